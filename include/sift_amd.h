@@ -1,0 +1,250 @@
+/*
+ * sift_amd.h -- C ABI of libsift_amd.so, the MI355X (gfx950) implementation of the
+ * `sift_anatomy` hot path.
+ *
+ * Part 1 declares the structs and entry points of the reference with identical names,
+ * layouts, argument meaning and ownership rules, so existing C host code (sift_cli.c,
+ * lib_sift.c callers, example.c) links against this library instead of
+ * lib_sift_anatomy.o / lib_discrete.o / lib_description.o.  Each declaration cites the
+ * reference interface it replaces (paths relative to sift_anatomy/src/).
+ *
+ * Part 2 is this library's own batched interface: a context that owns a pyramid pool in
+ * HBM and processes N same-sized images per call, returning only the final keypoints.
+ *
+ * All pointers are plain host pointers unless a parameter is named d_* (device memory).
+ * Every keypoint, descriptor, histogram, list, octave and image stack handed to the
+ * caller through Part 1 is an individual libc malloc block, because callers release
+ * them with sift_free_keypoints / sift_free_scalespace (lib_keypoint.c:167-182,
+ * lib_scalespace.c:139-151).
+ */
+#ifndef SIFT_AMD_H
+#define SIFT_AMD_H
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================== Part 1 == */
+
+/* lib_sift_anatomy.h:63-67 */
+struct sift_parameters {
+    int n_oct, n_spo, n_hist, n_bins, n_ori, itermax;
+    float sigma_min, delta_min, sigma_in, C_DoG, C_edge, lambda_ori, t, lambda_descr;
+};
+
+/* lib_keypoint.h:76-96 */
+struct keypoint {
+    float x;      /* row coordinate, input-image pixels */
+    float y;      /* column coordinate */
+    float sigma;
+    float theta;
+    int o, s, i, j;
+    float val;
+    float edgeResp;
+    int n_hist;
+    int n_ori;
+    float* descr;    /* n_hist*n_hist*n_ori floats holding 0..255 after quantisation */
+    int n_bins;
+    float* orihist;  /* n_bins floats */
+};
+
+/* lib_keypoint.h:106-110 */
+struct sift_keypoints {
+    int size;
+    int capacity;
+    struct keypoint** list;
+};
+
+/* lib_scalespace.h:62-74 */
+struct octa {
+    float delta;
+    int w;
+    int h;
+    int nSca;
+    float* sigmas;
+    float* imStack;  /* nSca images of w*h samples, scale-major */
+};
+struct sift_scalespace {
+    int nOct;
+    struct octa* octaves[100];
+};
+
+/* lib_sift.h:73-80 */
+struct sift_keypoint_std {
+    float x, y, scale, orientation;
+    unsigned char descriptor[128];
+};
+
+/* lib_sift_anatomy.h:69  (lib_sift_anatomy.c:771-789) */
+struct sift_parameters* sift_assign_default_parameters(void);
+
+/* lib_sift_anatomy.h:71-73  (lib_sift_anatomy.c:818-875).
+ * ss[0..3] receive gss, dog, d/di, d/dj scale-spaces; kk[0..5] (pre-allocated by the caller
+ * with sift_malloc_keypoints) receive the six intermediate lists. */
+struct sift_keypoints* sift_anatomy(const float* x, int w, int h, const struct sift_parameters* p,
+                                    struct sift_scalespace* ss[4], struct sift_keypoints* kk[6]);
+
+/* lib_sift_anatomy.h:75-77  (lib_sift_anatomy.c:879-926) */
+struct sift_keypoints* sift_anatomy_without_description(const float* x, int w, int h,
+                                                        const struct sift_parameters* p,
+                                                        struct sift_scalespace* ss[2],
+                                                        struct sift_keypoints* kk[5]);
+
+/* lib_sift_anatomy.h:79  (lib_sift_anatomy.c:931-949): descriptors for given oriented keypoints */
+void sift_anatomy_only_description(const float* x, int w, int h, const struct sift_parameters* p,
+                                   struct sift_keypoints* k);
+
+/* lib_sift_anatomy.h:81  (lib_sift_anatomy.c:953-975): one orientation + descriptor per keypoint */
+void sift_anatomy_orientation_and_description(const float* x, int w, int h,
+                                              const struct sift_parameters* p,
+                                              struct sift_keypoints* k);
+
+/* lib_sift_anatomy.h:84-88  (lib_sift_anatomy.c:96-161): fills the image stacks of a
+ * pre-allocated Gaussian scale-space */
+void scalespace_compute(struct sift_scalespace* ss, const float* image, int im_w, int im_h,
+                        float sigma_in);
+
+/* lib_sift_anatomy.h:90-92  (lib_sift_anatomy.c:202-218) */
+void scalespace_compute_gradient(const struct sift_scalespace* scalespace,
+                                 struct sift_scalespace* sx, struct sift_scalespace* sy);
+
+/* lib_sift.h:91-112  (lib_sift.c:140-285): flat API with default parameters */
+struct sift_keypoint_std* sift_compute_points(const float* x, int w, int h, int* n);
+struct sift_keypoint_std* sift_compute_features(const float* x, int w, int h, int* n);
+void sift_fill_descriptors(const float* x, int w, int h, struct sift_keypoint_std* k, int n);
+void sift_find_ori_and_fill_descriptors(const float* x, int w, int h, struct sift_keypoint_std* k, int n);
+
+/* lib_sift.h:115-123  (lib_sift.c:287-367): keypoint text format */
+void fprintf_keypoint_std(FILE* f, const struct sift_keypoint_std* k, int n);
+void sift_write_to_file(const char* filename, const struct sift_keypoint_std* k, int n);
+struct sift_keypoint_std* sift_read_from_file(const char* filename, int* n);
+struct sift_keypoint_std* sift_read_keyslocation_from_file(char* filename, int* n);
+
+/* Containers: lib_keypoint.h:98-147 (lib_keypoint.c:75-297), lib_scalespace.h:79-95
+ * (lib_scalespace.c:122-297).  Exported so hosts need not compile the reference's
+ * container files; a host that does keeps using its own (same malloc/free contract). */
+struct keypoint* sift_malloc_keypoint(int n_ori, int n_hist, int n_bins);
+struct keypoint* sift_malloc_keypoint_from_model_and_copy(const struct keypoint* key);
+struct sift_keypoints* sift_malloc_keypoints(void);
+void sift_add_keypoint_to_list(struct keypoint* key, struct sift_keypoints* keys);
+void sift_free_keypoint(struct keypoint* key);
+void sift_free_keypoints(struct sift_keypoints* keys);
+void fprintf_one_keypoint(FILE* f, const struct keypoint* k, int n_descr, int n_bins, int flag);
+void fprintf_keypoints(FILE* f, const struct sift_keypoints* keys, int flag);
+void sift_save_keypoints(const struct sift_keypoints* keys, const char* name, int flag);
+void sift_print_keypoints(const struct sift_keypoints* keys, int flag);
+void sift_read_keypoints(struct sift_keypoints* keys, const char* name, int n_hist, int n_ori,
+                         int n_bins, int flag);
+struct sift_scalespace* sift_malloc_scalespace(int nOct, const float* deltas, const int* ws,
+                                               const int* hs, const int* nScas, float** sigmas);
+void sift_free_scalespace(struct sift_scalespace* sift_scalespace);
+struct sift_scalespace* sift_malloc_scalespace_from_model(struct sift_scalespace* model);
+struct sift_scalespace* sift_malloc_scalespace_dog_from_scalespace(struct sift_scalespace* scalespace);
+struct sift_scalespace* sift_malloc_scalespace_lowe(int nOct, int nSca, int im_w, int im_h,
+                                                    float delta_min, float sigma_min);
+
+/* ===================================================================== Part 2 == */
+/* No counterpart in the reference: batched, context-based interface.  Functions return 0
+ * on success and a negative value on failure; sift_amd_last_error() describes the failure
+ * of the calling thread's last call. */
+
+typedef struct sift_amd_ctx sift_amd_ctx;
+
+#define SIFT_AMD_MAX_OCT 16
+#define SIFT_AMD_MAX_SCA 12
+
+enum {
+    SIFT_AMD_KEEP_ALL_EXTREMA = 1  /* list every discrete extremum (needed to reproduce kk[0]);
+                                      default keeps only those passing the first contrast test */
+};
+
+/* Kernel classes for the built-in event timers. */
+enum {
+    SIFT_AMD_K_OVERSAMPLE = 0, SIFT_AMD_K_SUBSAMPLE, SIFT_AMD_K_BLUR_V, SIFT_AMD_K_BLUR_H,
+    SIFT_AMD_K_EXTREMA, SIFT_AMD_K_REFINE, SIFT_AMD_K_RANK, SIFT_AMD_K_ORIENTATION,
+    SIFT_AMD_K_EXPAND, SIFT_AMD_K_DESCRIPTOR, SIFT_AMD_K_COUNT
+};
+
+struct sift_amd_geometry {
+    int n_oct, n_sca;                       /* n_sca Gaussian, n_sca-1 DoG images per octave */
+    int w[SIFT_AMD_MAX_OCT], h[SIFT_AMD_MAX_OCT];
+    float delta[SIFT_AMD_MAX_OCT];
+    float sigmas[SIFT_AMD_MAX_OCT][SIFT_AMD_MAX_SCA];
+    int blur_radius[SIFT_AMD_MAX_OCT][SIFT_AMD_MAX_SCA];  /* [o][0] is the seed blur (octave 0 only) */
+    float thresh_pre, thresh, thresh_edge;
+};
+
+/* 40-byte keypoint record used for stage lists and final keys. */
+struct sift_amd_key {
+    float x, y, sigma, theta;
+    int o, s, i, j;
+    float val, edge;
+};
+
+const char* sift_amd_last_error(void);
+int sift_amd_device_count(void);
+
+/* Allocates the pyramid pool for up to max_batch images of w x h on `device`.
+ * p == NULL selects the default parameters.  Returns NULL on failure. */
+sift_amd_ctx* sift_amd_create(int device, int w, int h, int max_batch,
+                              const struct sift_parameters* p, int flags);
+void sift_amd_destroy(sift_amd_ctx* ctx);
+int sift_amd_get_geometry(const sift_amd_ctx* ctx, struct sift_amd_geometry* g);
+
+/* Runs the whole pipeline on n <= max_batch images already resident in device memory
+ * (float32, row-major, [n][h][w]).  Asynchronous: work is queued on `stream` (a hipStream_t
+ * passed as void*; NULL = the context's own stream).  d_images must stay valid until the
+ * next synchronising call. */
+int sift_amd_detect_device(sift_amd_ctx* ctx, const float* d_images, int n, void* stream);
+
+/* Same for host images: copies them to the device first. */
+int sift_amd_detect_host(sift_amd_ctx* ctx, const float* images, int n);
+
+/* Scale-space only (oversample, blurs, DoG) on device-resident images. */
+int sift_amd_scalespace_device(sift_amd_ctx* ctx, const float* d_images, int n, void* stream);
+
+/* Waits for the last run, then reports per image the number of final keypoints. */
+int sift_amd_keypoint_counts(sift_amd_ctx* ctx, int* counts /* [n] */);
+
+/* Copies the final keypoints of image `img` (call sift_amd_keypoint_counts first).
+ * Either output may be NULL.  Returns the number of keypoints copied. */
+int sift_amd_fetch_keypoints(sift_amd_ctx* ctx, int img, struct sift_keypoint_std* out_std,
+                             struct sift_amd_key* out_keys, int max_keys);
+
+/* Host gather: all keypoints of the last run, image after image, into one malloc'd array
+ * (caller frees with free()); counts[i] receives the per-image counts. */
+int sift_amd_gather_keypoints(sift_amd_ctx* ctx, struct sift_keypoint_std** out, int* counts);
+
+/* Stage-level access for parity tooling.  stage_sizes[0..5] are the sizes of the lists
+ * A..F of lib_sift_anatomy.c:843-848, extrema_per_octave the discrete-extrema counts. */
+int sift_amd_stage_counts(sift_amd_ctx* ctx, int img, int stage_sizes[6],
+                          int extrema_per_octave[SIFT_AMD_MAX_OCT]);
+/* Candidate records in canonical (o,s,i,j)-of-seed order with the last stage each reached
+ * (0=A .. 5=F).  Returns the number written; with all three outputs NULL, the number
+ * available.  Without SIFT_AMD_KEEP_ALL_EXTREMA the candidates are list B. */
+int sift_amd_fetch_candidates(sift_amd_ctx* ctx, int img, struct sift_amd_key* seed,
+                              struct sift_amd_key* refined, int* stage, int max_n);
+/* which: 0 = Gaussian stack (n_sca images), 1 = DoG stack (n_sca-1 images) of one octave. */
+int sift_amd_copy_scalespace(sift_amd_ctx* ctx, int img, int which, int octave, float* dst);
+/* Per final keypoint: smoothed orientation histogram (n_bins floats), float descriptor
+ * (n_hist*n_hist*n_ori floats holding 0..255) and the rank, within list F, of the keypoint
+ * it was derived from.  Any output may be NULL.  Returns the number of keypoints. */
+int sift_amd_fetch_extras(sift_amd_ctx* ctx, int img, float* orihist, float* descr, int* src_index,
+                          int max_keys);
+/* Smoothed orientation histograms of the list-F keypoints, in list order. */
+int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* ctx, int img, float* orihist, int max_n);
+/* Frees the context that the reference-named entry points keep per host thread. */
+void sift_amd_release_thread_cache(void);
+
+/* Event timers: enable for a mask of (1 << SIFT_AMD_K_*) classes; read accumulates since the
+ * last reset.  ms = summed kernel durations, launches = number of launches timed. */
+int sift_amd_profile_enable(sift_amd_ctx* ctx, unsigned mask);
+int sift_amd_profile_read(sift_amd_ctx* ctx, int kernel_class, int octave /* -1 = all */,
+                          double* ms, long long* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIFT_AMD_H */

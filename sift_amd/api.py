@@ -1,0 +1,258 @@
+"""ctypes front-end of libsift_amd.so.
+
+Two layers, both thin:
+  * `Context` wraps the batched interface (Part 2 of include/sift_amd.h);
+  * `lib()` returns the raw library with the reference-named entry points bound, so code
+    written against lib_sift_anatomy.h / lib_sift.h can call them unchanged.
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, calls fail.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsift_amd.so")
+
+MAX_OCT, MAX_SCA = 16, 12
+K_OVERSAMPLE, K_SUBSAMPLE, K_BLUR_V, K_BLUR_H, K_EXTREMA, K_REFINE, K_RANK, K_ORIENTATION, \
+    K_EXPAND, K_DESCRIPTOR, K_COUNT = range(11)
+KERNEL_CLASSES = ["oversample", "subsample", "blur_v", "blur_h", "extrema", "refine", "rank",
+                  "orientation", "expand", "descriptor"]
+KEEP_ALL_EXTREMA = 1
+
+
+class Geometry(C.Structure):
+    _fields_ = [("n_oct", C.c_int), ("n_sca", C.c_int),
+                ("w", C.c_int * MAX_OCT), ("h", C.c_int * MAX_OCT),
+                ("delta", C.c_float * MAX_OCT),
+                ("sigmas", (C.c_float * MAX_SCA) * MAX_OCT),
+                ("blur_radius", (C.c_int * MAX_SCA) * MAX_OCT),
+                ("thresh_pre", C.c_float), ("thresh", C.c_float), ("thresh_edge", C.c_float)]
+
+
+KEY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("sigma", "<f4"), ("theta", "<f4"),
+                      ("o", "<i4"), ("s", "<i4"), ("i", "<i4"), ("j", "<i4"),
+                      ("val", "<f4"), ("edge", "<f4")])
+assert KEY_DTYPE.itemsize == 40
+
+
+class SiftAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libsift_amd.so and declare every entry point.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SiftAmdError(f"{LIB_PATH} not found: build it with `python -m sift_amd.build` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    abi.bind_reference_api(L)
+    P = C.POINTER
+    vp = C.c_void_p
+    L.sift_amd_last_error.restype = C.c_char_p
+    L.sift_amd_device_count.restype = C.c_int
+    L.sift_amd_create.restype = vp
+    L.sift_amd_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, P(abi.SiftParameters), C.c_int]
+    L.sift_amd_destroy.restype = None
+    L.sift_amd_destroy.argtypes = [vp]
+    L.sift_amd_get_geometry.argtypes = [vp, P(Geometry)]
+    L.sift_amd_detect_device.argtypes = [vp, vp, C.c_int, vp]
+    L.sift_amd_detect_host.argtypes = [vp, abi.c_float_p, C.c_int]
+    L.sift_amd_scalespace_device.argtypes = [vp, vp, C.c_int, vp]
+    L.sift_amd_keypoint_counts.argtypes = [vp, abi.c_int_p]
+    L.sift_amd_fetch_keypoints.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.sift_amd_gather_keypoints.argtypes = [vp, P(vp), abi.c_int_p]
+    L.sift_amd_stage_counts.argtypes = [vp, C.c_int, abi.c_int_p, abi.c_int_p]
+    L.sift_amd_fetch_candidates.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+    L.sift_amd_copy_scalespace.argtypes = [vp, C.c_int, C.c_int, C.c_int, abi.c_float_p]
+    L.sift_amd_fetch_extras.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+    L.sift_amd_fetch_stage_f_histograms.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.sift_amd_profile_enable.argtypes = [vp, C.c_uint]
+    L.sift_amd_profile_read.argtypes = [vp, C.c_int, C.c_int, P(C.c_double), P(C.c_longlong), C.c_int]
+    L.sift_amd_release_thread_cache.restype = None
+    _lib = L
+    return L
+
+
+def _err(what):
+    return SiftAmdError(f"{what}: {lib().sift_amd_last_error().decode()}")
+
+
+def device_count():
+    return lib().sift_amd_device_count()
+
+
+class Context:
+    """Pyramid pool + pipeline for up to `max_batch` images of w x h on one GPU."""
+
+    def __init__(self, w, h, max_batch=1, params=None, device=0, keep_all_extrema=False):
+        self.L = lib()
+        self.w, self.h, self.max_batch = w, h, max_batch
+        self.params = params if params is not None else abi.SiftParameters.default()
+        flags = KEEP_ALL_EXTREMA if keep_all_extrema else 0
+        self.ptr = self.L.sift_amd_create(device, w, h, max_batch, C.byref(self.params), flags)
+        if not self.ptr:
+            raise _err("sift_amd_create")
+        g = Geometry()
+        self.L.sift_amd_get_geometry(self.ptr, C.byref(g))
+        self.geometry = g
+        self.n_oct, self.n_sca = g.n_oct, g.n_sca
+        self.dims = [(g.w[o], g.h[o]) for o in range(g.n_oct)]
+        self.last_n = 0
+
+    def close(self):
+        if self.ptr:
+            self.L.sift_amd_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- running
+    def detect_device(self, d_ptr, n, stream=None):
+        if self.L.sift_amd_detect_device(self.ptr, d_ptr, n, stream):
+            raise _err("sift_amd_detect_device")
+        self.last_n = n
+
+    def scalespace_device(self, d_ptr, n, stream=None):
+        if self.L.sift_amd_scalespace_device(self.ptr, d_ptr, n, stream):
+            raise _err("sift_amd_scalespace_device")
+        self.last_n = n
+
+    def detect_host(self, images):
+        images = np.ascontiguousarray(images, np.float32)
+        if images.ndim == 2:
+            images = images[None]
+        n, h, w = images.shape
+        if (w, h) != (self.w, self.h):
+            raise ValueError(f"image size {w}x{h} does not match the context ({self.w}x{self.h})")
+        if self.L.sift_amd_detect_host(self.ptr, images.ctypes.data_as(abi.c_float_p), n):
+            raise _err("sift_amd_detect_host")
+        self.last_n = n
+
+    # ---- results
+    def counts(self):
+        out = (C.c_int * max(self.last_n, 1))()
+        if self.L.sift_amd_keypoint_counts(self.ptr, out):
+            raise _err("sift_amd_keypoint_counts")
+        return np.array(out[:self.last_n], np.int64)
+
+    def keypoints(self, img=0):
+        """(std records (n,) KEYPOINT_STD_DTYPE, key records (n,) KEY_DTYPE) of one image."""
+        n = int(self.counts()[img])
+        std = np.zeros(n, abi.KEYPOINT_STD_DTYPE)
+        keys = np.zeros(n, KEY_DTYPE)
+        if n:
+            got = self.L.sift_amd_fetch_keypoints(self.ptr, img, std.ctypes.data, keys.ctypes.data, n)
+            if got != n:
+                raise _err("sift_amd_fetch_keypoints")
+        return std, keys
+
+    def gather(self):
+        """Host gather of the whole batch: (concatenated std records, per-image counts)."""
+        out = C.c_void_p()
+        cnt = (C.c_int * max(self.last_n, 1))()
+        if self.L.sift_amd_gather_keypoints(self.ptr, C.byref(out), cnt):
+            raise _err("sift_amd_gather_keypoints")
+        counts = np.array(cnt[:self.last_n], np.int64)
+        total = int(counts.sum())
+        arr = np.zeros(total, abi.KEYPOINT_STD_DTYPE)
+        if total:
+            C.memmove(arr.ctypes.data, out.value, total * 144)
+        C.CDLL(None).free(out)
+        return arr, counts
+
+    def extras(self, img=0):
+        n = int(self.counts()[img])
+        nb = self.params.n_bins
+        nd = self.params.n_hist ** 2 * self.params.n_ori
+        orih = np.zeros((n, nb), np.float32)
+        descr = np.zeros((n, nd), np.float32)
+        src = np.zeros(n, np.int32)
+        if n:
+            got = self.L.sift_amd_fetch_extras(self.ptr, img, orih.ctypes.data, descr.ctypes.data,
+                                               src.ctypes.data, n)
+            if got != n:
+                raise _err("sift_amd_fetch_extras")
+        return orih, descr, src
+
+    def stage_counts(self, img=0):
+        sizes = (C.c_int * 6)()
+        ext = (C.c_int * MAX_OCT)()
+        if self.L.sift_amd_stage_counts(self.ptr, img, sizes, ext):
+            raise _err("sift_amd_stage_counts")
+        return np.array(sizes[:], np.int64), np.array(ext[:self.n_oct], np.int64)
+
+    def candidates(self, img=0):
+        n = self.L.sift_amd_fetch_candidates(self.ptr, img, None, None, None, 0)
+        if n < 0:
+            raise _err("sift_amd_fetch_candidates")
+        seed = np.zeros(n, KEY_DTYPE)
+        ref = np.zeros(n, KEY_DTYPE)
+        stage = np.zeros(n, np.int32)
+        if n:
+            got = self.L.sift_amd_fetch_candidates(self.ptr, img, seed.ctypes.data, ref.ctypes.data,
+                                                   stage.ctypes.data, n)
+            if got != n:
+                raise _err("sift_amd_fetch_candidates")
+        return seed, ref, stage
+
+    def scalespace(self, img, which, octave):
+        """(n_images, h, w) float32 copy of the Gaussian (which=0) or DoG (which=1) stack."""
+        w, h = self.dims[octave]
+        nimg = self.n_sca if which == 0 else self.n_sca - 1
+        out = np.empty((nimg, h, w), np.float32)
+        if self.L.sift_amd_copy_scalespace(self.ptr, img, which, octave,
+                                           out.ctypes.data_as(abi.c_float_p)):
+            raise _err("sift_amd_copy_scalespace")
+        return out
+
+    # ---- event timers
+    def profile_enable(self, classes):
+        mask = 0
+        for c in classes:
+            mask |= 1 << c
+        self.L.sift_amd_profile_enable(self.ptr, mask)
+
+    def profile_read(self, cls, octave=-1, reset=False):
+        ms = C.c_double()
+        n = C.c_longlong()
+        if self.L.sift_amd_profile_read(self.ptr, cls, octave, C.byref(ms), C.byref(n), int(reset)):
+            raise _err("sift_amd_profile_read")
+        return ms.value, n.value
+
+    # ---- sizes of the work (for roofline accounting)
+    def pixels_per_octave(self):
+        return [w * h for (w, h) in self.dims]
+
+
+def sift_compute_features(img):
+    """lib_sift.h sift_compute_features on one image -> structured array of 144-byte records."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    n = C.c_int()
+    L = lib()
+    p = L.sift_compute_features(img.ctypes.data_as(abi.c_float_p), w, h, C.byref(n))
+    out = np.zeros(n.value, abi.KEYPOINT_STD_DTYPE)
+    if n.value:
+        C.memmove(out.ctypes.data, p, n.value * 144)
+    C.CDLL(None).free(C.cast(p, C.c_void_p))
+    return out

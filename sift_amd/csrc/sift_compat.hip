@@ -1,0 +1,654 @@
+// Part 1 of include/sift_amd.h: the reference-named entry points, implemented on top of
+// the batched context.  This layer only moves data: it runs the HIP pipeline and then
+// materialises the malloc-based structs that existing host code walks and frees itself.
+// Errors follow the reference's convention (message on stderr, abort/exit), because the
+// reference signatures have no error channel.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/sift_amd.h"
+#include "sift_ctx.h"
+#include "sift_launch.h"
+
+[[noreturn]] static void die(const char* what)
+{
+    fprintf(stderr, "sift_amd: %s: %s\n", what, sift_amd_last_error());
+    abort();
+}
+
+static int env_device()
+{
+    const char* s = getenv("SIFT_AMD_DEVICE");
+    return s ? atoi(s) : 0;
+}
+
+// ------------------------------------------------------ per-thread context --
+// The reference API is stateless; allocating the HBM pool on every call would dominate
+// small calls, so each host thread keeps the context of its last (size, parameters, mode).
+struct CachedCtx {
+    sift_amd_ctx* ctx = nullptr;
+    int w = 0, h = 0, flags = 0, device = -1;
+    sift_parameters p;
+    bool lowe = true;
+    SaLayout L;
+    float sigma_in = 0;
+    ~CachedCtx() { if (ctx) sift_amd_destroy(ctx); }
+};
+static thread_local CachedCtx g_cache;
+
+static sift_amd_ctx* get_ctx(int w, int h, const sift_parameters* p, int flags)
+{
+    CachedCtx& cc = g_cache;
+    const int dev = env_device();
+    if (cc.ctx && cc.lowe && cc.w == w && cc.h == h && cc.flags == flags && cc.device == dev &&
+        memcmp(&cc.p, p, sizeof *p) == 0)
+        return cc.ctx;
+    if (cc.ctx) { sift_amd_destroy(cc.ctx); cc.ctx = nullptr; }
+    sift_amd_ctx* c = sift_amd_create(dev, w, h, 1, p, flags);
+    if (!c) die("cannot create context");
+    cc.ctx = c; cc.w = w; cc.h = h; cc.flags = flags; cc.device = dev; cc.p = *p; cc.lowe = true;
+    return c;
+}
+
+extern "C" void sift_amd_release_thread_cache(void)
+{
+    if (g_cache.ctx) { sift_amd_destroy(g_cache.ctx); g_cache.ctx = nullptr; }
+}
+
+// -------------------------------------------------------------- containers --
+// Same allocation contract as lib_keypoint.c:75-182 and lib_scalespace.c:91-151: every
+// object is its own malloc block.
+
+static void* must_malloc(size_t n)
+{
+    void* p = malloc(n ? n : 1);
+    if (!p) { fprintf(stderr, "sift_amd: out of host memory (%zu bytes)\n", n); abort(); }
+    return p;
+}
+
+extern "C" struct keypoint* sift_malloc_keypoint(int n_ori, int n_hist, int n_bins)
+{
+    struct keypoint* k = (struct keypoint*)must_malloc(sizeof *k);
+    memset(k, 0, sizeof *k);
+    k->n_ori = n_ori; k->n_hist = n_hist; k->n_bins = n_bins;
+    const int nd = n_ori * n_hist * n_hist;
+    k->descr = (float*)must_malloc(nd * sizeof(float));
+    k->orihist = (float*)must_malloc(n_bins * sizeof(float));
+    for (int n = 0; n < nd; n++) k->descr[n] = 0.f;
+    for (int n = 0; n < n_bins; n++) k->orihist[n] = 0.f;
+    return k;
+}
+
+extern "C" struct keypoint* sift_malloc_keypoint_from_model_and_copy(const struct keypoint* src)
+{
+    struct keypoint* k = sift_malloc_keypoint(src->n_ori, src->n_hist, src->n_bins);
+    k->x = src->x; k->y = src->y; k->sigma = src->sigma; k->theta = src->theta;
+    k->o = src->o; k->s = src->s; k->i = src->i; k->j = src->j;
+    k->val = src->val; k->edgeResp = src->edgeResp;
+    memcpy(k->descr, src->descr, sizeof(float) * src->n_ori * src->n_hist * src->n_hist);
+    memcpy(k->orihist, src->orihist, sizeof(float) * src->n_bins);
+    return k;
+}
+
+extern "C" struct sift_keypoints* sift_malloc_keypoints(void)
+{
+    struct sift_keypoints* l = (struct sift_keypoints*)must_malloc(sizeof *l);
+    l->capacity = 100;                       // lib_keypoint.c:142-144
+    l->size = 0;
+    l->list = (struct keypoint**)must_malloc(l->capacity * sizeof(struct keypoint*));
+    return l;
+}
+
+extern "C" void sift_add_keypoint_to_list(struct keypoint* key, struct sift_keypoints* keys)
+{
+    if (keys->size > keys->capacity - 1) {   // doubling growth, lib_keypoint.c:149-164
+        keys->capacity *= 2;
+        keys->list = (struct keypoint**)realloc(keys->list, keys->capacity * sizeof(struct keypoint*));
+        if (!keys->list) { fprintf(stderr, "sift_amd: realloc failed\n"); abort(); }
+    }
+    keys->list[keys->size++] = key;
+}
+
+extern "C" void sift_free_keypoint(struct keypoint* key)
+{
+    free(key->orihist);
+    free(key->descr);
+    free(key);
+}
+
+extern "C" void sift_free_keypoints(struct sift_keypoints* keys)
+{
+    for (int k = 0; k < keys->size; k++) sift_free_keypoint(keys->list[k]);
+    free(keys->list);
+    free(keys);
+}
+
+extern "C" struct sift_scalespace* sift_malloc_scalespace(int nOct, const float* deltas, const int* ws,
+                                                           const int* hs, const int* nScas, float** sigmas)
+{
+    struct sift_scalespace* ss = (struct sift_scalespace*)must_malloc(sizeof *ss);
+    ss->nOct = nOct;
+    for (int o = 0; o < nOct; o++) {
+        struct octa* oc = (struct octa*)must_malloc(sizeof *oc);
+        oc->delta = deltas[o]; oc->w = ws[o]; oc->h = hs[o]; oc->nSca = nScas[o];
+        oc->sigmas = (float*)must_malloc(nScas[o] * sizeof(float));
+        oc->imStack = (float*)must_malloc((size_t)nScas[o] * ws[o] * hs[o] * sizeof(float));
+        for (int s = 0; s < nScas[o]; s++) oc->sigmas[s] = sigmas[o][s];
+        ss->octaves[o] = oc;
+    }
+    return ss;
+}
+
+extern "C" void sift_free_scalespace(struct sift_scalespace* ss)
+{
+    for (int o = 0; o < ss->nOct; o++) {
+        free(ss->octaves[o]->sigmas);
+        free(ss->octaves[o]->imStack);
+        free(ss->octaves[o]);
+    }
+    free(ss);
+}
+
+// shape = model's octave sizes with `drop` fewer images per octave (lib_scalespace.c:164-198, 266-297)
+static struct sift_scalespace* scalespace_like(const struct sift_scalespace* m, int drop)
+{
+    const int n = m->nOct;
+    std::vector<float> deltas(n);
+    std::vector<int> ws(n), hs(n), ns(n);
+    std::vector<float*> sig(n);
+    for (int o = 0; o < n; o++) {
+        deltas[o] = m->octaves[o]->delta; ws[o] = m->octaves[o]->w; hs[o] = m->octaves[o]->h;
+        ns[o] = m->octaves[o]->nSca - drop;
+        sig[o] = m->octaves[o]->sigmas;
+    }
+    return sift_malloc_scalespace(n, deltas.data(), ws.data(), hs.data(), ns.data(), sig.data());
+}
+
+extern "C" struct sift_scalespace* sift_malloc_scalespace_from_model(struct sift_scalespace* m)
+{
+    return scalespace_like(m, 0);
+}
+
+extern "C" struct sift_scalespace* sift_malloc_scalespace_dog_from_scalespace(struct sift_scalespace* m)
+{
+    return scalespace_like(m, 1);
+}
+
+static struct sift_scalespace* scalespace_from_layout(const SaLayout* L, int drop)
+{
+    std::vector<int> ns(L->n_oct, L->n_sca - drop);
+    std::vector<float*> sig(L->n_oct);
+    for (int o = 0; o < L->n_oct; o++) sig[o] = const_cast<float*>(L->sigmas[o]);
+    return sift_malloc_scalespace(L->n_oct, L->delta, L->w, L->h, ns.data(), sig.data());
+}
+
+extern "C" struct sift_scalespace* sift_malloc_scalespace_lowe(int nOct, int nSca, int im_w, int im_h,
+                                                                float delta_min, float sigma_min)
+{
+    if (nOct > SA_MAX_OCT || nSca + 3 > SA_MAX_SCA || nOct < 0) {
+        fprintf(stderr, "sift_amd: scale-space shape %d octaves x %d scales unsupported\n", nOct, nSca);
+        abort();
+    }
+    SaLayout L;
+    memset(&L, 0, sizeof L);
+    sa_layout_lowe(&L, nOct, nSca, im_w, im_h, delta_min, sigma_min);
+    return scalespace_from_layout(&L, 0);
+}
+
+// ------------------------------------------------------------- conversions --
+
+static struct keypoint* key_from_record(const sift_amd_key& r, const sift_parameters* p)
+{
+    struct keypoint* k = sift_malloc_keypoint(p->n_ori, p->n_hist, p->n_bins);
+    k->x = r.x; k->y = r.y; k->sigma = r.sigma; k->theta = r.theta;
+    k->o = r.o; k->s = r.s; k->i = r.i; k->j = r.j;
+    k->val = r.val; k->edgeResp = r.edge;
+    return k;
+}
+
+static void download_stack(sift_amd_ctx* c, int which, struct sift_scalespace* ss)
+{
+    for (int o = 0; o < ss->nOct; o++)
+        if (sift_amd_copy_scalespace(c, 0, which, o, ss->octaves[o]->imStack)) die("copy scale-space");
+}
+
+// d/di and d/dj of every image of a host scale-space (lib_sift_anatomy.c:202-218).
+static void gradient_stacks(const struct sift_scalespace* s, struct sift_scalespace* sx, struct sift_scalespace* sy)
+{
+    if (hipSetDevice(env_device()) != hipSuccess) { sa_set_error("hipSetDevice failed"); die("gradient"); }
+    size_t biggest = 0;
+    for (int o = 0; o < s->nOct; o++) {
+        const struct octa* oc = s->octaves[o];
+        biggest = std::max(biggest, (size_t)oc->nSca * oc->w * oc->h);
+    }
+    float *d_im = nullptr, *d_gi = nullptr, *d_gj = nullptr;
+    if (hipMalloc((void**)&d_im, biggest * 4) != hipSuccess || hipMalloc((void**)&d_gi, biggest * 4) != hipSuccess ||
+        hipMalloc((void**)&d_gj, biggest * 4) != hipSuccess) { sa_set_error("hipMalloc failed"); die("gradient"); }
+    for (int o = 0; o < s->nOct; o++) {
+        const struct octa* oc = s->octaves[o];
+        const size_t bytes = (size_t)oc->nSca * oc->w * oc->h * 4;
+        bool ok = hipMemcpy(d_im, oc->imStack, bytes, hipMemcpyHostToDevice) == hipSuccess;
+        sa::launch_gradient(nullptr, d_im, d_gi, d_gj, oc->w, oc->h, oc->nSca);
+        ok = ok && hipMemcpy(sx->octaves[o]->imStack, d_gi, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hipMemcpy(sy->octaves[o]->imStack, d_gj, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) { sa_set_error("gradient transfer failed: %s", hipGetErrorString(hipGetLastError())); die("gradient"); }
+    }
+    (void)hipFree(d_im); (void)hipFree(d_gi); (void)hipFree(d_gj);
+}
+
+// ---------------------------------------------------------- reference API --
+
+extern "C" struct sift_parameters* sift_assign_default_parameters(void)
+{
+    struct sift_parameters* p = (struct sift_parameters*)must_malloc(sizeof *p);
+    sa_default_parameters(p);
+    return p;
+}
+
+// Runs detection (+ description) for one host image and fills the intermediate lists.
+// n_lists = 6 for sift_anatomy (A..F), 5 for the variant without description (A..E).
+static struct sift_keypoints* run_full(const float* x, int w, int h, const sift_parameters* p,
+                                       struct sift_scalespace** ss, int n_ss, struct sift_keypoints** kk,
+                                       int n_lists, bool describe)
+{
+    sift_amd_ctx* c = get_ctx(w, h, p, SIFT_AMD_KEEP_ALL_EXTREMA);
+    hipStream_t st = sa_ctx_stream(c);
+    if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+        sa_set_error("input upload failed");
+        die("sift_anatomy");
+    }
+    int rc;
+    if (describe) {
+        rc = sift_amd_detect_device(c, sa_ctx_input_buffer(c), 1, nullptr);
+    } else {
+        rc = sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr);
+        if (!rc) rc = sa_run_detect(c, 1, st);
+    }
+    if (rc) die("pipeline");
+    if (sa_sync_counters(c)) die("pipeline");
+
+    const SaLayout* L = sa_ctx_layout(c);
+    // scale-spaces
+    ss[0] = scalespace_from_layout(L, 0);
+    ss[1] = scalespace_from_layout(L, 1);
+    download_stack(c, 0, ss[0]);
+    download_stack(c, 1, ss[1]);
+    if (n_ss == 4) {
+        ss[2] = scalespace_from_layout(L, 0);
+        ss[3] = scalespace_from_layout(L, 0);
+        gradient_stacks(ss[0], ss[2], ss[3]);
+    }
+
+    // stage lists, in canonical order
+    int sizes[6], ext_oct[SIFT_AMD_MAX_OCT];
+    if (sift_amd_stage_counts(c, 0, sizes, ext_oct)) die("stage counts");
+    const int n = sizes[0];
+    std::vector<sift_amd_key> seed(n), ref(n);
+    std::vector<int> stage(n);
+    const int got = sift_amd_fetch_candidates(c, 0, seed.data(), ref.data(), stage.data(), n);
+    if (got != n) { sa_set_error("candidate list truncated (%d of %d)", got, n); die("sift_anatomy"); }
+
+    const int nb = p->n_bins, nd = p->n_hist * p->n_hist * p->n_ori;
+    int n_keys = 0;
+    std::vector<sift_amd_key> keys;
+    std::vector<float> descr, fhist;
+    std::vector<int> src;
+    if (describe) {
+        if (sift_amd_keypoint_counts(c, &n_keys)) die("counts");
+        keys.resize(n_keys); descr.resize((size_t)n_keys * nd); src.resize(n_keys);
+        if (n_keys) {
+            if (sift_amd_fetch_keypoints(c, 0, nullptr, keys.data(), n_keys) != n_keys) die("fetch keys");
+            if (sift_amd_fetch_extras(c, 0, nullptr, descr.data(), src.data(), n_keys) != n_keys) die("fetch extras");
+        }
+        fhist.resize((size_t)sizes[5] * nb);
+        if (sizes[5] && sift_amd_fetch_stage_f_histograms(c, 0, fhist.data(), sizes[5]) != sizes[5]) die("fetch histograms");
+    }
+
+    struct sift_keypoints* result = sift_malloc_keypoints();
+    int f_rank = 0, key_pos = 0;
+    for (int r = 0; r < n; r++) {
+        sift_add_keypoint_to_list(key_from_record(seed[r], p), kk[0]);
+        if (stage[r] >= 1) sift_add_keypoint_to_list(key_from_record(seed[r], p), kk[1]);
+        sift_amd_key q = ref[r];
+        const float edge = q.edge;
+        q.edge = 0.f;
+        if (stage[r] >= 2) sift_add_keypoint_to_list(key_from_record(q, p), kk[2]);
+        q.edge = edge;
+        if (stage[r] >= 3) sift_add_keypoint_to_list(key_from_record(q, p), kk[3]);
+        if (stage[r] >= 4) sift_add_keypoint_to_list(key_from_record(q, p), kk[4]);
+        if (stage[r] >= 5) {
+            struct keypoint* kf = key_from_record(q, p);
+            if (describe) {
+                // the reference accumulates the histogram inside the list-F entry and copies it
+                // into every oriented keypoint derived from it (lib_sift_anatomy.c:628-640)
+                const float* hist = &fhist[(size_t)f_rank * nb];
+                memcpy(kf->orihist, hist, nb * sizeof(float));
+                while (key_pos < n_keys && src[key_pos] == f_rank) {
+                    struct keypoint* kfin = key_from_record(keys[key_pos], p);
+                    memcpy(kfin->orihist, hist, nb * sizeof(float));
+                    memcpy(kfin->descr, &descr[(size_t)key_pos * nd], nd * sizeof(float));
+                    sift_add_keypoint_to_list(kfin, result);
+                    key_pos++;
+                }
+            }
+            if (n_lists == 6) sift_add_keypoint_to_list(kf, kk[5]);
+            else sift_add_keypoint_to_list(kf, result);
+            f_rank++;
+        }
+    }
+    return result;
+}
+
+extern "C" struct sift_keypoints* sift_anatomy(const float* x, int w, int h, const struct sift_parameters* p,
+                                               struct sift_scalespace* ss[4], struct sift_keypoints* kk[6])
+{
+    return run_full(x, w, h, p, ss, 4, kk, 6, true);
+}
+
+extern "C" struct sift_keypoints* sift_anatomy_without_description(const float* x, int w, int h,
+                                                                   const struct sift_parameters* p,
+                                                                   struct sift_scalespace* ss[2],
+                                                                   struct sift_keypoints* kk[5])
+{
+    return run_full(x, w, h, p, ss, 2, kk, 5, false);
+}
+
+static void describe_list(const float* x, int w, int h, const sift_parameters* p, struct sift_keypoints* k,
+                          bool find_orientation)
+{
+    sift_amd_ctx* c = get_ctx(w, h, p, 0);
+    hipStream_t st = sa_ctx_stream(c);
+    if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+        sa_set_error("input upload failed");
+        die("describe");
+    }
+    if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr)) die("scale-space");
+    const SaLayout* L = sa_ctx_layout(c);
+    const int n = k->size;
+    std::vector<SaKey> in(n);
+    for (int q = 0; q < n; q++) {
+        const struct keypoint* kp = k->list[q];
+        if (kp->o < 0 || kp->o >= L->n_oct || kp->s < 0 || kp->s >= L->n_sca) {
+            sa_set_error("keypoint %d refers to octave %d scale %d outside the scale-space", q, kp->o, kp->s);
+            die("describe");
+        }
+        SaKey& r = in[q];
+        r.x = kp->x; r.y = kp->y; r.sigma = kp->sigma; r.theta = kp->theta;
+        r.o = kp->o; r.s = kp->s; r.i = kp->i; r.j = kp->j; r.val = kp->val; r.edge = kp->edgeResp;
+    }
+    if (sa_describe_given(c, in.data(), n, find_orientation)) die("describe");
+    const int nb = p->n_bins, nd = p->n_hist * p->n_hist * p->n_ori;
+    std::vector<sift_amd_key> out(n);
+    std::vector<float> orihist((size_t)n * nb), descr((size_t)n * nd);
+    if (n) {
+        if (sift_amd_fetch_keypoints(c, 0, nullptr, out.data(), n) != n) die("fetch keys");
+        if (sift_amd_fetch_extras(c, 0, find_orientation ? orihist.data() : nullptr, descr.data(), nullptr, n) != n) die("fetch extras");
+    }
+    for (int q = 0; q < n; q++) {
+        struct keypoint* kp = k->list[q];
+        if (find_orientation) {
+            kp->theta = out[q].theta;
+            memcpy(kp->orihist, &orihist[(size_t)q * nb], nb * sizeof(float));
+        }
+        memcpy(kp->descr, &descr[(size_t)q * nd], nd * sizeof(float));
+    }
+}
+
+extern "C" void sift_anatomy_only_description(const float* x, int w, int h, const struct sift_parameters* p,
+                                              struct sift_keypoints* k)
+{
+    describe_list(x, w, h, p, k, false);
+}
+
+extern "C" void sift_anatomy_orientation_and_description(const float* x, int w, int h,
+                                                         const struct sift_parameters* p,
+                                                         struct sift_keypoints* k)
+{
+    describe_list(x, w, h, p, k, true);
+}
+
+extern "C" void scalespace_compute(struct sift_scalespace* ss, const float* image, int im_w, int im_h,
+                                   float sigma_in)
+{
+    SaLayout L;
+    memset(&L, 0, sizeof L);
+    if (ss->nOct < 1 || ss->nOct > SA_MAX_OCT) { sa_set_error("%d octaves unsupported", ss->nOct); die("scalespace_compute"); }
+    L.n_oct = ss->nOct;
+    L.n_sca = ss->octaves[0]->nSca;
+    if (L.n_sca > SA_MAX_SCA) { sa_set_error("%d scales unsupported", L.n_sca); die("scalespace_compute"); }
+    for (int o = 0; o < ss->nOct; o++) {
+        const struct octa* oc = ss->octaves[o];
+        if (oc->nSca != L.n_sca) { sa_set_error("octaves with different numbers of scales"); die("scalespace_compute"); }
+        L.w[o] = oc->w; L.h[o] = oc->h; L.delta[o] = oc->delta;
+        for (int s = 0; s < oc->nSca; s++) L.sigmas[o][s] = oc->sigmas[s];
+    }
+    // the checks of lib_sift_anatomy.c:108-109
+    if (L.w[0] != (int)((float)im_w / L.delta[0]) || L.h[0] != (int)((float)im_h / L.delta[0])) {
+        sa_set_error("scale-space does not match the image size");
+        die("scalespace_compute");
+    }
+    sift_parameters p;
+    sa_default_parameters(&p);
+    p.n_spo = L.n_sca - 3; p.delta_min = L.delta[0]; p.sigma_min = L.sigmas[0][0]; p.sigma_in = sigma_in;
+    sift_amd_ctx* c = sa_create_from_layout(env_device(), im_w, im_h, 1, &p, &L, sigma_in, 0);
+    if (!c) die("scalespace_compute");
+    if (hipMemcpy(sa_ctx_input_buffer(c), image, (size_t)im_w * im_h * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        sa_set_error("input upload failed");
+        die("scalespace_compute");
+    }
+    if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr)) die("scalespace_compute");
+    download_stack(c, 0, ss);
+    sift_amd_destroy(c);
+}
+
+extern "C" void scalespace_compute_gradient(const struct sift_scalespace* s, struct sift_scalespace* sx,
+                                            struct sift_scalespace* sy)
+{
+    gradient_stacks(s, sx, sy);
+}
+
+// ------------------------------------------------ flat API (lib_sift.c) ----
+
+extern "C" struct sift_keypoint_std* sift_compute_features(const float* x, int w, int h, int* n)
+{
+    sift_parameters p;
+    sa_default_parameters(&p);
+    sift_amd_ctx* c = get_ctx(w, h, &p, 0);
+    if (sift_amd_detect_host(c, x, 1)) die("sift_compute_features");
+    int cnt = 0;
+    if (sift_amd_keypoint_counts(c, &cnt)) die("sift_compute_features");
+    struct sift_keypoint_std* k = (struct sift_keypoint_std*)must_malloc((size_t)cnt * sizeof *k);
+    if (cnt && sift_amd_fetch_keypoints(c, 0, k, nullptr, cnt) != cnt) die("sift_compute_features");
+    *n = cnt;
+    return k;
+}
+
+// Keypoints after the border filter, orientation 0 and empty descriptors: what
+// lib_sift.c:192-236 returns (it calls the variant without description).
+extern "C" struct sift_keypoint_std* sift_compute_points(const float* x, int w, int h, int* n)
+{
+    sift_parameters p;
+    sa_default_parameters(&p);
+    sift_amd_ctx* c = get_ctx(w, h, &p, 0);
+    hipStream_t st = sa_ctx_stream(c);
+    if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+        sa_set_error("input upload failed");
+        die("sift_compute_points");
+    }
+    if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr) || sa_run_detect(c, 1, st)) die("sift_compute_points");
+    int sizes[6], ext[SIFT_AMD_MAX_OCT];
+    if (sift_amd_stage_counts(c, 0, sizes, ext)) die("sift_compute_points");
+    const int nc = sift_amd_fetch_candidates(c, 0, nullptr, nullptr, nullptr, 0);   // list B
+    if (nc < 0) die("sift_compute_points");
+    std::vector<sift_amd_key> ref(nc);
+    std::vector<int> stage(nc);
+    if (sift_amd_fetch_candidates(c, 0, nullptr, ref.data(), stage.data(), nc) != nc) die("sift_compute_points");
+    struct sift_keypoint_std* k = (struct sift_keypoint_std*)must_malloc((size_t)sizes[5] * sizeof *k);
+    int m = 0;
+    for (int r = 0; r < nc; r++)
+        if (stage[r] >= 5) {
+            memset(&k[m], 0, sizeof k[m]);
+            k[m].x = ref[r].x; k[m].y = ref[r].y; k[m].scale = ref[r].sigma; k[m].orientation = 0.f;
+            m++;
+        }
+    *n = m;
+    return k;
+}
+
+// Infers (o,s,i,j) from the scale as lib_sift.c:73-113 does.
+static struct sift_keypoints* std_to_list(const struct sift_keypoint_std* k, int n, const sift_parameters* p)
+{
+    struct sift_keypoints* keys = sift_malloc_keypoints();
+    for (int q = 0; q < n; q++) {
+        struct keypoint* key = sift_malloc_keypoint(p->n_ori, p->n_hist, p->n_bins);
+        key->x = k[q].x; key->y = k[q].y; key->sigma = k[q].scale; key->theta = k[q].orientation;
+        int o, s;
+        const int a = (int)(round(p->n_spo * log((double)(k[q].scale / p->sigma_min)) / 0.693147180559945309417));
+        o = (a - 1) / p->n_spo;
+        if (o > -1) { s = (a - 1) % p->n_spo + 1; } else { o = 0; s = 0; }
+        key->o = o; key->s = s;
+        const double d = (double)p->delta_min * exp(o * 0.693147180559945309417);
+        key->i = (int)((double)key->x / d + 0.5);
+        key->j = (int)((double)key->y / d + 0.5);
+        sift_add_keypoint_to_list(key, keys);
+    }
+    return keys;
+}
+
+static void list_to_std(const struct sift_keypoints* keys, struct sift_keypoint_std* k)
+{
+    for (int q = 0; q < keys->size; q++) {
+        const struct keypoint* key = keys->list[q];
+        k[q].x = key->x; k[q].y = key->y; k[q].scale = key->sigma; k[q].orientation = key->theta;
+        for (int j = 0; j < 128; j++) k[q].descriptor[j] = (unsigned char)(key->descr[j]);
+    }
+}
+
+extern "C" void sift_fill_descriptors(const float* x, int w, int h, struct sift_keypoint_std* k, int n)
+{
+    sift_parameters p;
+    sa_default_parameters(&p);
+    struct sift_keypoints* keys = std_to_list(k, n, &p);
+    sift_anatomy_only_description(x, w, h, &p, keys);
+    list_to_std(keys, k);
+    sift_free_keypoints(keys);
+}
+
+extern "C" void sift_find_ori_and_fill_descriptors(const float* x, int w, int h, struct sift_keypoint_std* k, int n)
+{
+    sift_parameters p;
+    sa_default_parameters(&p);
+    struct sift_keypoints* keys = std_to_list(k, n, &p);
+    sift_anatomy_orientation_and_description(x, w, h, &p, keys);
+    list_to_std(keys, k);
+    sift_free_keypoints(keys);
+}
+
+// ------------------------------------------- keypoint text format (I/O) ----
+// lib_keypoint.c:184-297, lib_sift.c:287-367.
+
+extern "C" void fprintf_one_keypoint(FILE* f, const struct keypoint* k, int n_descr, int n_bins, int flag)
+{
+    fprintf(f, "%f %f %f %f ", k->x, k->y, k->sigma, k->theta);
+    if (flag > 0)
+        for (int n = 0; n < n_descr; n++) fprintf(f, "%i ", (int)k->descr[n]);
+    if (flag > 1)
+        for (int n = 0; n < n_bins; n++) fprintf(f, "%f ", k->orihist[n]);
+}
+
+extern "C" void fprintf_keypoints(FILE* f, const struct sift_keypoints* keys, int flag)
+{
+    if (keys->size <= 0) return;
+    const struct keypoint* k0 = keys->list[0];
+    const int n_descr = k0->n_hist * k0->n_hist * k0->n_ori, n_bins = k0->n_bins;
+    for (int k = 0; k < keys->size; k++) {
+        fprintf_one_keypoint(f, keys->list[k], n_descr, n_bins, flag);
+        fprintf(f, "\n");
+    }
+}
+
+extern "C" void sift_save_keypoints(const struct sift_keypoints* keys, const char* name, int flag)
+{
+    FILE* f = fopen(name, "w");
+    if (!f) { fprintf(stderr, "Fatal error: Failed to open %s for writing\n\n", name); exit(1); }
+    fprintf_keypoints(f, keys, flag);
+    fclose(f);
+}
+
+extern "C" void sift_print_keypoints(const struct sift_keypoints* keys, int flag)
+{
+    fprintf_keypoints(stdout, keys, flag);
+}
+
+extern "C" void sift_read_keypoints(struct sift_keypoints* keys, const char* name, int n_hist, int n_ori,
+                                    int n_bins, int flag)
+{
+    const size_t cap = 1024 * 1024;
+    char* line = (char*)must_malloc(cap);
+    FILE* f = fopen(name, "r");
+    if (!f) { fprintf(stderr, "Fatal error: File \"%s\" not found.\n", name); exit(1); }
+    while (fgets(line, (int)cap, f)) {
+        int pos = 0, used = 0;
+        struct keypoint* key = sift_malloc_keypoint(n_ori, n_hist, n_bins);
+        sscanf(line + pos, "%f  %f  %f  %f %n", &key->x, &key->y, &key->sigma, &key->theta, &used);
+        pos += used;
+        if (flag > 0)
+            for (int i = 0; i < n_hist * n_hist * n_ori; i++) {
+                sscanf(line + pos, "%f %n", &key->descr[i], &used);
+                pos += used;
+            }
+        if (flag > 1)
+            for (int i = 0; i < n_bins; i++) {
+                sscanf(line + pos, "%f %n", &key->orihist[i], &used);
+                pos += used;
+            }
+        sift_add_keypoint_to_list(key, keys);
+    }
+    fclose(f);
+    free(line);
+}
+
+extern "C" void fprintf_keypoint_std(FILE* f, const struct sift_keypoint_std* k, int n)
+{
+    for (int i = 0; i < n; i++) {
+        fprintf(f, "%f %f %f %f ", k[i].x, k[i].y, k[i].scale, k[i].orientation);
+        for (int j = 0; j < 128; j++) fprintf(f, "%u ", k[i].descriptor[j]);
+        fprintf(f, "\n");
+    }
+}
+
+extern "C" void sift_write_to_file(const char* filename, const struct sift_keypoint_std* k, int n)
+{
+    FILE* f = fopen(filename, "w");
+    if (!f) { fprintf(stderr, "Fatal error: Failed to open %s for writing\n\n", filename); exit(1); }
+    fprintf_keypoint_std(f, k, n);
+    fclose(f);
+}
+
+static struct sift_keypoint_std* read_std(const char* filename, int* n, int flag)
+{
+    sift_parameters p;
+    sa_default_parameters(&p);
+    struct sift_keypoints* keys = sift_malloc_keypoints();
+    sift_read_keypoints(keys, filename, p.n_hist, p.n_ori, p.n_bins, flag);
+    *n = keys->size;
+    struct sift_keypoint_std* k = (struct sift_keypoint_std*)must_malloc((size_t)keys->size * sizeof *k);
+    list_to_std(keys, k);
+    sift_free_keypoints(keys);
+    return k;
+}
+
+extern "C" struct sift_keypoint_std* sift_read_from_file(const char* filename, int* n)
+{
+    return read_std(filename, n, 1);
+}
+
+extern "C" struct sift_keypoint_std* sift_read_keyslocation_from_file(char* filename, int* n)
+{
+    return read_std(filename, n, 0);
+}

@@ -1,0 +1,760 @@
+// Host side of the batched pipeline: context, HBM pool, launch sequence, transfers.
+// Implements Part 2 of include/sift_amd.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/sift_amd.h"
+#include "sift_ctx.h"
+#include "sift_launch.h"
+
+static_assert(sizeof(sift_amd_key) == sizeof(SaKey), "key record layout");
+static_assert(sizeof(sift_keypoint_std) == sizeof(SaStd) && sizeof(SaStd) == 144, "std record layout");
+static_assert(SIFT_AMD_MAX_OCT == SA_MAX_OCT && SIFT_AMD_MAX_SCA == SA_MAX_SCA, "limits");
+
+static thread_local char g_err[512] = "";
+
+void sa_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* sift_amd_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            sa_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+extern "C" int sift_amd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------- parameters --
+// Scalar conversions done exactly as the reference does them on the host.
+
+static const double kLn2 = 0.693147180559945309417;
+
+void sa_default_parameters(sift_parameters* p)   // lib_sift_anatomy.c:771-789
+{
+    p->n_oct = 8; p->n_spo = 3;
+    p->sigma_min = 0.8; p->delta_min = 0.5; p->sigma_in = 0.5;
+    p->C_DoG = 0.013333333; p->C_edge = 10;
+    p->n_bins = 36; p->lambda_ori = 1.5; p->t = 0.80;
+    p->n_hist = 4; p->n_ori = 8; p->lambda_descr = 6; p->itermax = 5;
+}
+
+int sa_number_of_octaves(int w, int h, const sift_parameters* p)   // lib_sift_anatomy.c:793-802
+{
+    int hmin = 12;
+    int h0 = (int)((float)std::min(w, h) / p->delta_min);
+    if (h0 / hmin < 1) return 0;
+    int n = (int)(log((double)(h0 / hmin)) / kLn2) + 1;
+    return std::min(p->n_oct, n);
+}
+
+float sa_convert_threshold(const sift_parameters* p)   // lib_sift_anatomy.c:807-814
+{
+    float k_nspo = (float)exp(kLn2 / (double)((float)p->n_spo));
+    float k_3 = (float)exp(kLn2 / (double)((float)3));
+    return (k_nspo - 1) / (k_3 - 1) * p->C_DoG;
+}
+
+// lib_discrete.c:145-164,172-174
+static int gaussian_taps(float sigma, std::vector<float>& g)
+{
+    int rad = (int)ceil((double)(4 * sigma));
+    if (rad < 0) rad = 0;
+    g.assign(rad + 1, 0.f);
+    g[0] = 1.f;
+    if (sigma > 0) {
+        float sum = g[0];
+        for (int i = 1; i <= rad; i++) {
+            g[i] = (float)exp(-0.5 * (double)(float)i * (double)(float)i / (double)sigma / (double)sigma);
+            sum += 2 * g[i];
+        }
+        for (int i = 0; i <= rad; i++) g[i] /= sum;
+    }
+    return rad;
+}
+
+void sa_layout_lowe(SaLayout* L, int n_oct, int n_spo, int im_w, int im_h, float delta_min,
+                    float sigma_min)   // lib_scalespace.c:216-252
+{
+    L->n_oct = n_oct;
+    L->n_sca = n_spo + 3;
+    L->delta[0] = delta_min;
+    L->h[0] = (int)((float)im_h / delta_min);
+    L->w[0] = (int)((float)im_w / delta_min);
+    for (int o = 1; o < n_oct; o++) {
+        L->w[o] = L->w[o - 1] / 2;
+        L->h[o] = L->h[o - 1] / 2;
+        L->delta[o] = (float)(L->delta[o - 1] * 2.0);
+    }
+    for (int o = 0; o < n_oct; o++)
+        for (int s = 0; s < n_spo + 3; s++)
+            L->sigmas[o][s] = (float)((double)(L->delta[o] / L->delta[0] * sigma_min)
+                                      * pow(2.0, (double)((float)s / (float)n_spo)));
+}
+
+// ----------------------------------------------------------------- context --
+
+struct BlurSpec {
+    float sigma;
+    int radius;
+    SaTaps taps;
+    float* taps_dev;
+};
+
+struct ProfEvent { hipEvent_t a, b; int cls, oct; };
+
+struct sift_amd_ctx {
+    int device = 0;
+    int im_w = 0, im_h = 0, batch = 0, flags = 0;
+    sift_parameters p;
+    SaLayout L;
+    float sigma_in = 0.f;
+    SaPyramid pyr;
+    SaScalars sc;
+    BlurSpec seed;
+    BlurSpec step[SA_MAX_OCT][SA_MAX_SCA];
+    hipStream_t own_stream = nullptr;
+    hipStream_t last_stream = nullptr;
+    int last_n = 0;
+
+    float *d_in = nullptr, *d_seed = nullptr, *d_tmp = nullptr;
+    float* d_gss[SA_MAX_OCT] = {};
+    float* d_dog[SA_MAX_OCT] = {};
+    int cap = 0, fcap = 0, kcap = 0;
+    unsigned long long* d_ckey = nullptr;
+    float* d_cval = nullptr;
+    SaKey* d_ref = nullptr;
+    int* d_stage = nullptr;
+    int* d_counters = nullptr;
+    int* d_flist = nullptr;
+    SaKey* d_given = nullptr;       // keypoints supplied by the caller (description-only entry points)
+    int* d_ori_n = nullptr;
+    float *d_ori_theta = nullptr, *d_ori_hist = nullptr;
+    SaKey* d_keys = nullptr;
+    int* d_key_src = nullptr;
+    SaStd* d_std = nullptr;
+    float* d_descr = nullptr;
+    int* h_counters = nullptr;      // pinned
+    bool counters_valid = false;
+    std::vector<void*> allocs;
+
+    unsigned prof_mask = 0;
+    std::vector<ProfEvent> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[SIFT_AMD_K_COUNT][SA_MAX_OCT + 1] = {};
+    long long prof_n[SIFT_AMD_K_COUNT][SA_MAX_OCT + 1] = {};
+};
+
+template <typename T>
+static int dev_alloc(sift_amd_ctx* c, T** p, size_t count)
+{
+    void* v = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&v, bytes);
+    if (e != hipSuccess) {
+        sa_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return -1;
+    }
+    c->allocs.push_back(v);
+    *p = (T*)v;
+    return 0;
+}
+
+static int make_blur(sift_amd_ctx* c, BlurSpec* b, float sigma)
+{
+    std::vector<float> g;
+    b->sigma = sigma;
+    b->radius = gaussian_taps(sigma, g);
+    memset(&b->taps, 0, sizeof b->taps);
+    b->taps_dev = nullptr;
+    if (b->radius <= SA_MAX_RADIUS_FAST) {
+        for (int k = 0; k <= b->radius; k++) b->taps.g[k] = g[k];
+    }
+    if (b->radius < 1 || b->radius > SA_MAX_RADIUS_FAST) {
+        if (b->radius >= SA_MAX_TAPS) {
+            sa_set_error("blur radius %d (sigma %g) exceeds the supported maximum %d", b->radius, sigma, SA_MAX_TAPS - 1);
+            return -1;
+        }
+        if (dev_alloc(c, &b->taps_dev, g.size())) return -1;
+        HIP_TRY(hipMemcpy(b->taps_dev, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static long long total_pixels(const SaLayout& L)
+{
+    long long n = 0;
+    for (int o = 0; o < L.n_oct; o++) n += (long long)L.w[o] * L.h[o];
+    return n;
+}
+
+sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batch, const sift_parameters* p,
+                                    const SaLayout* L, float sigma_in, int flags)
+{
+    if (max_batch < 1 || im_w < 1 || im_h < 1) { sa_set_error("invalid size or batch"); return nullptr; }
+    if (L->n_oct < 1 || L->n_oct > SA_MAX_OCT) {
+        sa_set_error("number of octaves %d outside 1..%d (image %dx%d too small or n_oct too large)",
+                     L->n_oct, SA_MAX_OCT, im_w, im_h);
+        return nullptr;
+    }
+    if (L->n_sca < 4 || L->n_sca > SA_MAX_SCA) { sa_set_error("n_spo must be in 1..%d", SA_MAX_SCA - 3); return nullptr; }
+    if (p->n_bins < 3 || p->n_bins > SA_MAX_BINS) { sa_set_error("n_bins must be in 3..%d", SA_MAX_BINS); return nullptr; }
+    if (p->n_hist < 1 || p->n_ori < 2 || p->n_hist * p->n_hist * p->n_ori > SA_MAX_DESCR) {
+        sa_set_error("descriptor shape n_hist=%d n_ori=%d unsupported (n_ori>=2, n_hist^2*n_ori<=%d)",
+                     p->n_hist, p->n_ori, SA_MAX_DESCR);
+        return nullptr;
+    }
+    if (!(p->delta_min <= 1.f) || !(p->delta_min > 0.f)) { sa_set_error("delta_min must be in (0,1]"); return nullptr; }
+    if (!(L->sigmas[0][0] >= sigma_in)) { sa_set_error("sigma_min must be >= sigma_in"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { sa_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+
+    sift_amd_ctx* c = new sift_amd_ctx();
+    c->device = device; c->im_w = im_w; c->im_h = im_h; c->batch = max_batch; c->flags = flags;
+    c->p = *p; c->L = *L; c->sigma_in = sigma_in;
+    auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
+
+    for (int o = 1; o < L->n_oct; o++)
+        if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
+            sa_set_error("octave %d is not the previous octave halved", o);
+            return fail();
+        }
+
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        sa_set_error("hipStreamCreate failed");
+        return fail();
+    }
+
+    // blur schedule: lib_sift_anatomy.c:132 (seed) and :155-158 (steps)
+    {
+        float smin = L->sigmas[0][0], dmin = L->delta[0];
+        float se = (float)(sqrt((double)(smin * smin - sigma_in * sigma_in)) / (double)dmin);
+        if (make_blur(c, &c->seed, se)) return fail();
+        for (int o = 0; o < L->n_oct; o++)
+            for (int s = 1; s < L->n_sca; s++) {
+                float sp = L->sigmas[o][s - 1], sn = L->sigmas[o][s];
+                float sx = (float)(sqrt((double)(sn * sn - sp * sp)) / (double)L->delta[o]);
+                if (make_blur(c, &c->step[o][s], sx)) return fail();
+            }
+    }
+
+    // scalars
+    float thresh = sa_convert_threshold(p);
+    c->sc.thr = thresh;
+    c->sc.thr_pre = (float)(0.8 * (double)thresh);                      // lib_sift_anatomy.c:855
+    c->sc.thr_edge = (p->C_edge + 1) * (p->C_edge + 1) / p->C_edge;     // lib_sift_anatomy.c:859
+    c->sc.sigma_ratio = L->sigmas[0][1] / L->sigmas[0][0];              // lib_sift_anatomy.c:436
+    c->sc.lambda_ori = p->lambda_ori; c->sc.t_peak = p->t; c->sc.lambda_descr = p->lambda_descr;
+    c->sc.itermax = p->itermax; c->sc.n_bins = p->n_bins; c->sc.n_hist = p->n_hist; c->sc.n_ori = p->n_ori;
+
+    // HBM pool
+    const long long n0 = (long long)L->w[0] * L->h[0];
+    const long long ntot = total_pixels(*L);
+    const long long B = max_batch;
+    if (dev_alloc(c, &c->d_in, (size_t)(B * im_w * im_h))) return fail();
+    if (dev_alloc(c, &c->d_seed, (size_t)(B * n0))) return fail();
+    if (dev_alloc(c, &c->d_tmp, (size_t)(B * n0))) return fail();
+    memset(&c->pyr, 0, sizeof c->pyr);
+    c->pyr.n_oct = L->n_oct; c->pyr.n_sca = L->n_sca; c->pyr.im_w = im_w; c->pyr.im_h = im_h;
+    for (int o = 0; o < L->n_oct; o++) {
+        const long long n = (long long)L->w[o] * L->h[o];
+        if (dev_alloc(c, &c->d_gss[o], (size_t)(B * L->n_sca * n))) return fail();
+        if (dev_alloc(c, &c->d_dog[o], (size_t)(B * (L->n_sca - 1) * n))) return fail();
+        SaOctave& oc = c->pyr.oct[o];
+        oc.gss = c->d_gss[o]; oc.dog = c->d_dog[o];
+        oc.gss_stride = L->n_sca * n; oc.dog_stride = (L->n_sca - 1) * n;
+        oc.w = L->w[o]; oc.h = L->h[o]; oc.delta = L->delta[o];
+        for (int s = 0; s < L->n_sca; s++) oc.sigmas[s] = L->sigmas[o][s];
+    }
+    long long cap = (flags & SIFT_AMD_KEEP_ALL_EXTREMA) ? ntot / 8 : ntot / 64;
+    cap = std::max<long long>(cap, 16384);
+    cap = std::min<long long>(cap, 1 << 24);
+    c->cap = (int)cap;
+    c->fcap = (int)std::max<long long>(4096, cap / 4);
+    c->kcap = 2 * c->fcap;
+    if (dev_alloc(c, &c->d_ckey, (size_t)(B * c->cap))) return fail();
+    if (dev_alloc(c, &c->d_cval, (size_t)(B * c->cap))) return fail();
+    if (dev_alloc(c, &c->d_ref, (size_t)(B * c->cap))) return fail();
+    if (dev_alloc(c, &c->d_stage, (size_t)(B * c->cap))) return fail();
+    if (dev_alloc(c, &c->d_counters, (size_t)(B * SA_CNT_STRIDE))) return fail();
+    if (dev_alloc(c, &c->d_flist, (size_t)(B * c->fcap))) return fail();
+    if (dev_alloc(c, &c->d_given, (size_t)(B * c->fcap))) return fail();
+    if (dev_alloc(c, &c->d_ori_n, (size_t)(B * c->fcap))) return fail();
+    if (dev_alloc(c, &c->d_ori_theta, (size_t)(B * c->fcap * SA_MAX_PEAKS))) return fail();
+    if (dev_alloc(c, &c->d_ori_hist, (size_t)(B * c->fcap * SA_MAX_BINS))) return fail();
+    if (dev_alloc(c, &c->d_keys, (size_t)(B * c->kcap))) return fail();
+    if (dev_alloc(c, &c->d_key_src, (size_t)(B * c->kcap))) return fail();
+    if (dev_alloc(c, &c->d_std, (size_t)(B * c->kcap))) return fail();
+    if (dev_alloc(c, &c->d_descr, (size_t)(B * c->kcap * SA_MAX_DESCR))) return fail();
+    if (hipHostMalloc((void**)&c->h_counters, (size_t)B * SA_CNT_STRIDE * sizeof(int)) != hipSuccess) {
+        sa_set_error("hipHostMalloc failed");
+        return fail();
+    }
+    return c;
+}
+
+extern "C" sift_amd_ctx* sift_amd_create(int device, int w, int h, int max_batch,
+                                         const sift_parameters* p_in, int flags)
+{
+    sift_parameters p;
+    if (p_in) p = *p_in; else sa_default_parameters(&p);
+    if (p.n_spo < 1 || p.n_spo + 3 > SA_MAX_SCA) { sa_set_error("n_spo must be in 1..%d", SA_MAX_SCA - 3); return nullptr; }
+    SaLayout L;
+    memset(&L, 0, sizeof L);
+    int n_oct = sa_number_of_octaves(w, h, &p);
+    if (n_oct < 1 || n_oct > SA_MAX_OCT) {
+        sa_set_error("image %dx%d gives %d octaves (supported 1..%d)", w, h, n_oct, SA_MAX_OCT);
+        return nullptr;
+    }
+    sa_layout_lowe(&L, n_oct, p.n_spo, w, h, p.delta_min, p.sigma_min);
+    return sa_create_from_layout(device, w, h, max_batch, &p, &L, p.sigma_in, flags);
+}
+
+extern "C" void sift_amd_destroy(sift_amd_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& e : c->prof_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+    for (auto& e : c->prof_pool) hipEventDestroy(e);
+    for (void* v : c->allocs) hipFree(v);
+    if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int sift_amd_get_geometry(const sift_amd_ctx* c, sift_amd_geometry* g)
+{
+    memset(g, 0, sizeof *g);
+    g->n_oct = c->L.n_oct; g->n_sca = c->L.n_sca;
+    for (int o = 0; o < c->L.n_oct; o++) {
+        g->w[o] = c->L.w[o]; g->h[o] = c->L.h[o]; g->delta[o] = c->L.delta[o];
+        for (int s = 0; s < c->L.n_sca; s++) {
+            g->sigmas[o][s] = c->L.sigmas[o][s];
+            g->blur_radius[o][s] = s ? c->step[o][s].radius : (o == 0 ? c->seed.radius : 0);
+        }
+    }
+    g->thresh_pre = c->sc.thr_pre; g->thresh = c->sc.thr; g->thresh_edge = c->sc.thr_edge;
+    return 0;
+}
+
+// --------------------------------------------------------------- profiling --
+
+struct ProfScope {
+    sift_amd_ctx* c; hipStream_t st; ProfEvent ev; bool on;
+    ProfScope(sift_amd_ctx* c_, hipStream_t st_, int cls, int oct) : c(c_), st(st_), on(false)
+    {
+        if (!(c->prof_mask & (1u << cls))) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else hipEventCreate(&e);
+            return e;
+        };
+        ev.a = get(); ev.b = get(); ev.cls = cls; ev.oct = oct;
+        hipEventRecord(ev.a, st);
+        on = true;
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        hipEventRecord(ev.b, st);
+        c->prof_pending.push_back(ev);
+    }
+};
+
+static void prof_collect(sift_amd_ctx* c)
+{
+    for (auto& e : c->prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->prof_ms[e.cls][e.oct] += ms; c->prof_n[e.cls][e.oct] += 1;
+        }
+        c->prof_pool.push_back(e.a); c->prof_pool.push_back(e.b);
+    }
+    c->prof_pending.clear();
+}
+
+extern "C" int sift_amd_profile_enable(sift_amd_ctx* c, unsigned mask) { c->prof_mask = mask; return 0; }
+
+extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, double* ms, long long* launches, int reset)
+{
+    if (cls < 0 || cls >= SIFT_AMD_K_COUNT || octave >= SA_MAX_OCT) { sa_set_error("bad class/octave"); return -1; }
+    hipSetDevice(c->device);
+    prof_collect(c);
+    double t = 0; long long n = 0;
+    for (int o = 0; o < SA_MAX_OCT; o++)
+        if (octave < 0 || octave == o) {
+            t += c->prof_ms[cls][o]; n += c->prof_n[cls][o];
+            if (reset) { c->prof_ms[cls][o] = 0; c->prof_n[cls][o] = 0; }
+        }
+    if (ms) *ms = t;
+    if (launches) *launches = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------- pipeline --
+
+static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
+                     float* out, long long s_out, float* dog, long long s_dog, int n)
+{
+    sa::BlurArgs a;
+    a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog;
+    a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog;
+    a.w = c->L.w[o]; a.h = c->L.h[o]; a.batch = n;
+    a.radius = b.radius; a.taps = b.taps; a.taps_dev = b.taps_dev;
+    sa::launch_blur_profiled(st, a, c, o);
+}
+
+namespace sa {
+void launch_blur_profiled(hipStream_t st, const BlurArgs& a, sift_amd_ctx* c, int o)
+{
+    if (c->prof_mask & ((1u << SIFT_AMD_K_BLUR_V) | (1u << SIFT_AMD_K_BLUR_H))) {
+        { ProfScope ps(c, st, SIFT_AMD_K_BLUR_V, o); launch_blur_pass(st, a, 0); }
+        { ProfScope ps(c, st, SIFT_AMD_K_BLUR_H, o); launch_blur_pass(st, a, 1); }
+    } else {
+        launch_blur_pass(st, a, 0);
+        launch_blur_pass(st, a, 1);
+    }
+}
+}  // namespace sa
+
+int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st)
+{
+    const SaLayout& L = c->L;
+    const int ns = L.n_sca;
+    for (int o = 0; o < L.n_oct; o++) {
+        const long long np = (long long)L.w[o] * L.h[o];
+        const long long sg = ns * np, sd = (ns - 1) * np;
+        float* g = c->d_gss[o];
+        float* d = c->d_dog[o];
+        if (o == 0) {
+            if (L.delta[0] < 1.f) {
+                { ProfScope ps(c, st, SIFT_AMD_K_OVERSAMPLE, 0);
+                  sa::launch_oversample(st, d_images, c->im_w, c->im_h, (long long)c->im_w * c->im_h,
+                                        c->d_seed, L.w[0], L.h[0], np, L.delta[0], n); }
+                run_blur(c, st, 0, c->seed, c->d_seed, np, g, sg, nullptr, 0, n);
+            } else {
+                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, n);
+            }
+        } else {
+            const long long npp = (long long)L.w[o - 1] * L.h[o - 1];
+            ProfScope ps(c, st, SIFT_AMD_K_SUBSAMPLE, o);
+            sa::launch_subsample(st, c->d_gss[o - 1] + (ns - 3) * npp, L.w[o - 1], ns * npp,
+                                 g, L.w[o], L.h[o], sg, n);
+        }
+        for (int s = 1; s < ns; s++)
+            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, n);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sa_set_error("scale-space launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
+{
+    const SaLayout& L = c->L;
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, (size_t)n * SA_CNT_STRIDE * sizeof(int), st));
+    const int emit_all = (c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) ? 1 : 0;
+    for (int o = 0; o < L.n_oct; o++) {
+        const long long np = (long long)L.w[o] * L.h[o];
+        ProfScope ps(c, st, SIFT_AMD_K_EXTREMA, o);
+        if (sa::launch_extrema(st, c->d_dog[o], (L.n_sca - 1) * np, L.w[o], L.h[o], L.n_sca - 1, o,
+                               c->sc.thr_pre, emit_all, c->d_ckey, c->d_cval, c->d_counters, c->cap, n)) {
+            sa_set_error("unsupported number of DoG images %d", L.n_sca - 1);
+            return -1;
+        }
+    }
+    { ProfScope ps(c, st, SIFT_AMD_K_REFINE, 0);
+      sa::launch_refine(st, c->pyr, c->sc, c->d_ckey, c->d_cval, c->d_counters, c->cap, c->d_ref, c->d_stage, n); }
+    { ProfScope ps(c, st, SIFT_AMD_K_RANK, 0);
+      sa::launch_rank(st, c->d_ckey, c->d_stage, c->d_counters, c->cap, c->d_flist, c->fcap, n); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sa_set_error("detection launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+// keys/index/cnt_slot select the keypoints to orient: detection output (d_ref through
+// d_flist) or caller-supplied keys (d_given).
+int sa_run_orient(sift_amd_ctx* c, int n, hipStream_t st, bool given, int mode)
+{
+    const SaKey* keys = given ? c->d_given : c->d_ref;
+    const int* index = given ? nullptr : c->d_flist;
+    const int kcap = given ? c->fcap : c->cap;
+    { ProfScope ps(c, st, SIFT_AMD_K_ORIENTATION, 0);
+      sa::launch_orientation(st, c->pyr, c->sc, keys, index, c->d_counters, SA_CNT_NF, kcap, c->fcap, mode,
+                             c->d_ori_n, c->d_ori_theta, c->d_ori_hist, n); }
+    { ProfScope ps(c, st, SIFT_AMD_K_EXPAND, 0);
+      sa::launch_expand(st, keys, index, c->d_counters, SA_CNT_NF, kcap, c->fcap, c->d_ori_n, c->d_ori_theta,
+                        c->d_keys, c->d_key_src, c->kcap, n); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sa_set_error("orientation launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+int sa_run_describe(sift_amd_ctx* c, int n, hipStream_t st)
+{
+    ProfScope ps(c, st, SIFT_AMD_K_DESCRIPTOR, 0);
+    sa::launch_descriptor(st, c->pyr, c->sc, c->d_keys, c->d_counters, SA_CNT_KEYS, c->kcap, c->d_std, c->d_descr, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { sa_set_error("descriptor launch failed: %s", hipGetErrorString(e)); return -1; }
+    return 0;
+}
+
+static hipStream_t pick_stream(sift_amd_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->own_stream; }
+
+static int begin_run(sift_amd_ctx* c, int n, hipStream_t st)
+{
+    if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    c->last_stream = st; c->last_n = n; c->counters_valid = false;
+    return 0;
+}
+
+extern "C" int sift_amd_scalespace_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
+{
+    hipStream_t st = pick_stream(c, stream);
+    if (begin_run(c, n, st)) return -1;
+    return sa_run_scalespace(c, d_images, n, st);
+}
+
+extern "C" int sift_amd_detect_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
+{
+    hipStream_t st = pick_stream(c, stream);
+    if (begin_run(c, n, st)) return -1;
+    if (sa_run_scalespace(c, d_images, n, st)) return -1;
+    if (sa_run_detect(c, n, st)) return -1;
+    if (sa_run_orient(c, n, st, false, 0)) return -1;
+    return sa_run_describe(c, n, st);
+}
+
+extern "C" int sift_amd_detect_host(sift_amd_ctx* c, const float* images, int n)
+{
+    if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->d_in, images, (size_t)n * c->im_w * c->im_h * sizeof(float),
+                           hipMemcpyHostToDevice, c->own_stream));
+    return sift_amd_detect_device(c, c->d_in, n, nullptr);
+}
+
+int sa_sync_counters(sift_amd_ctx* c)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->counters_valid) {
+        hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+        HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, (size_t)c->batch * SA_CNT_STRIDE * sizeof(int),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        c->counters_valid = true;
+        for (int b = 0; b < c->last_n; b++)
+            if (c->h_counters[b * SA_CNT_STRIDE + SA_CNT_OVERFLOW]) {
+                sa_set_error("candidate/keypoint list overflow on image %d (capacity %d/%d/%d)", b, c->cap, c->fcap, c->kcap);
+                return -2;
+            }
+    }
+    return 0;
+}
+
+extern "C" int sift_amd_keypoint_counts(sift_amd_ctx* c, int* counts)
+{
+    int r = sa_sync_counters(c);
+    if (r) return r;
+    for (int b = 0; b < c->last_n; b++) counts[b] = c->h_counters[b * SA_CNT_STRIDE + SA_CNT_KEYS];
+    return 0;
+}
+
+extern "C" int sift_amd_fetch_keypoints(sift_amd_ctx* c, int img, sift_keypoint_std* out_std,
+                                        sift_amd_key* out_keys, int max_keys)
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    if (sa_sync_counters(c)) return -1;
+    int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS], max_keys);
+    if (n > 0 && out_std)
+        HIP_TRY(hipMemcpy(out_std, c->d_std + (size_t)img * c->kcap, (size_t)n * sizeof(SaStd), hipMemcpyDeviceToHost));
+    if (n > 0 && out_keys)
+        HIP_TRY(hipMemcpy(out_keys, c->d_keys + (size_t)img * c->kcap, (size_t)n * sizeof(SaKey), hipMemcpyDeviceToHost));
+    return n;
+}
+
+extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** out, int* counts)
+{
+    if (sa_sync_counters(c)) return -1;
+    size_t total = 0;
+    for (int b = 0; b < c->last_n; b++) {
+        counts[b] = c->h_counters[b * SA_CNT_STRIDE + SA_CNT_KEYS];
+        total += counts[b];
+    }
+    sift_keypoint_std* buf = (sift_keypoint_std*)malloc(std::max<size_t>(total, 1) * sizeof(sift_keypoint_std));
+    if (!buf) { sa_set_error("out of host memory"); return -1; }
+    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    size_t off = 0;
+    for (int b = 0; b < c->last_n; b++) {
+        if (counts[b])
+            HIP_TRY(hipMemcpyAsync(buf + off, c->d_std + (size_t)b * c->kcap, (size_t)counts[b] * sizeof(SaStd),
+                                   hipMemcpyDeviceToHost, st));
+        off += counts[b];
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = buf;
+    return 0;
+}
+
+extern "C" int sift_amd_stage_counts(sift_amd_ctx* c, int img, int stage_sizes[6], int ext_oct[SIFT_AMD_MAX_OCT])
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    int r = sa_sync_counters(c);
+    if (r) return r;
+    const int* cnt = c->h_counters + img * SA_CNT_STRIDE;
+    for (int k = 0; k < 6; k++) stage_sizes[k] = cnt[SA_CNT_STAGE + k];
+    for (int o = 0; o < SA_MAX_OCT; o++) ext_oct[o] = cnt[SA_CNT_EXT_OCT + o];
+    return 0;
+}
+
+extern "C" int sift_amd_fetch_candidates(sift_amd_ctx* c, int img, sift_amd_key* seed, sift_amd_key* refined,
+                                         int* stage, int max_n)
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    if (sa_sync_counters(c)) return -1;
+    const int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_CAND], c->cap);
+    if (!seed && !refined && !stage) return n;
+    std::vector<unsigned long long> key(n);
+    std::vector<float> val(n);
+    std::vector<SaKey> ref(n);
+    std::vector<int> stg(n);
+    if (n) {
+        HIP_TRY(hipMemcpy(key.data(), c->d_ckey + (size_t)img * c->cap, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(val.data(), c->d_cval + (size_t)img * c->cap, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(ref.data(), c->d_ref + (size_t)img * c->cap, n * sizeof(SaKey), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(stg.data(), c->d_stage + (size_t)img * c->cap, n * sizeof(int), hipMemcpyDeviceToHost));
+    }
+    // canonical order = ascending packed (o,s,i,j) of the seed; keys are unique
+    std::vector<int> order(n);
+    for (int k = 0; k < n; k++) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    const int m = std::min(n, max_n);
+    for (int r = 0; r < m; r++) {
+        const int k = order[r];
+        if (seed) {
+            const int o = (int)(key[k] >> 44), s = (int)((key[k] >> 40) & 0xf);
+            const int i = (int)((key[k] >> 20) & 0xfffff), j = (int)(key[k] & 0xfffff);
+            sift_amd_key& q = seed[r];
+            q.o = o; q.s = s; q.i = i; q.j = j;
+            q.x = c->L.delta[o] * i; q.y = c->L.delta[o] * j;     // lib_sift_anatomy.c:303-304
+            q.sigma = c->L.sigmas[o][s]; q.theta = 0.f; q.val = val[k]; q.edge = 0.f;
+        }
+        if (refined) memcpy(&refined[r], &ref[k], sizeof(SaKey));
+        if (stage) stage[r] = stg[k];
+    }
+    return m;
+}
+
+extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int o, float* dst)
+{
+    if (img < 0 || img >= c->batch || o < 0 || o >= c->L.n_oct || which < 0 || which > 1) {
+        sa_set_error("bad image/octave/which");
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    const long long np = (long long)c->L.w[o] * c->L.h[o];
+    const int nimg = which == 0 ? c->L.n_sca : c->L.n_sca - 1;
+    const float* src = (which == 0 ? c->d_gss[o] : c->d_dog[o]) + (long long)img * nimg * np;
+    HIP_TRY(hipMemcpy(dst, src, (size_t)(nimg * np) * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int sift_amd_fetch_extras(sift_amd_ctx* c, int img, float* orihist, float* descr, int* src_index,
+                                     int max_keys)
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    if (sa_sync_counters(c)) return -1;
+    const int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS], max_keys);
+    const int nb = c->p.n_bins, nd = c->p.n_hist * c->p.n_hist * c->p.n_ori;
+    if (n && descr) {
+        std::vector<float> tmp((size_t)n * SA_MAX_DESCR);
+        HIP_TRY(hipMemcpy(tmp.data(), c->d_descr + (size_t)img * c->kcap * SA_MAX_DESCR, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; k++) memcpy(descr + (size_t)k * nd, tmp.data() + (size_t)k * SA_MAX_DESCR, nd * sizeof(float));
+    }
+    if (n && (orihist || src_index)) {
+        const int nf = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_NF], c->fcap);
+        std::vector<float> hist((size_t)std::max(nf, 1) * SA_MAX_BINS);
+        std::vector<int> src(n);
+        HIP_TRY(hipMemcpy(hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, (size_t)nf * SA_MAX_BINS * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(src.data(), c->d_key_src + (size_t)img * c->kcap, n * sizeof(int), hipMemcpyDeviceToHost));
+        for (int k = 0; k < n; k++) {
+            if (orihist) memcpy(orihist + (size_t)k * nb, hist.data() + (size_t)src[k] * SA_MAX_BINS, nb * sizeof(float));
+            if (src_index) src_index[k] = src[k];
+        }
+    }
+    return n;
+}
+
+extern "C" int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* c, int img, float* orihist, int max_n)
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    if (sa_sync_counters(c)) return -1;
+    const int nf = std::min(std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_NF], c->fcap), max_n);
+    const int nb = c->p.n_bins;
+    if (nf && orihist) {
+        std::vector<float> hist((size_t)nf * SA_MAX_BINS);
+        HIP_TRY(hipMemcpy(hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, hist.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int k = 0; k < nf; k++) memcpy(orihist + (size_t)k * nb, hist.data() + (size_t)k * SA_MAX_BINS, nb * sizeof(float));
+    }
+    return nf;
+}
+
+// ---------------------------------------- entry points for caller-given keys --
+
+// Uploads `n` keypoints of image 0 and runs orientation (mode 1: one orientation each) and/or
+// description on them.  The scale-space of the last run must be resident.
+int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orientation)
+{
+    if (n > c->fcap) { sa_set_error("too many keypoints (%d > %d)", n, c->fcap); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->own_stream;
+    c->last_stream = st; c->last_n = 1; c->counters_valid = false;
+    int cnt[SA_CNT_STRIDE] = {0};
+    cnt[SA_CNT_NF] = n; cnt[SA_CNT_KEYS] = n;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(c->d_counters, cnt, sizeof cnt, hipMemcpyHostToDevice));
+    if (find_orientation) {
+        if (n) HIP_TRY(hipMemcpy(c->d_given, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
+        if (sa_run_orient(c, 1, st, true, 1)) return -1;
+    } else {
+        if (n) HIP_TRY(hipMemcpy(c->d_keys, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
+    }
+    if (sa_run_describe(c, 1, st)) return -1;
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int sa_ctx_limits(const sift_amd_ctx* c, int* cap, int* fcap, int* kcap)
+{
+    *cap = c->cap; *fcap = c->fcap; *kcap = c->kcap;
+    return 0;
+}
+const SaLayout* sa_ctx_layout(const sift_amd_ctx* c) { return &c->L; }
+const sift_parameters* sa_ctx_params(const sift_amd_ctx* c) { return &c->p; }
+float* sa_ctx_input_buffer(sift_amd_ctx* c) { return c->d_in; }
+hipStream_t sa_ctx_stream(sift_amd_ctx* c) { return c->own_stream; }

@@ -1,0 +1,986 @@
+// HIP kernels of the SIFT hot path for gfx950 (MI355X), wave64.
+//
+// Everything that feeds the DoG extrema decision is computed with the same float32
+// operation order as the reference C code and must be compiled with -ffp-contract=off:
+// one fused multiply-add in a blur changes last bits of the DoG and with them the set of
+// discrete extrema.  Histogram accumulation (orientation, descriptor) is done in raster
+// order per bin, exactly as a scalar loop would, so results do not depend on scheduling.
+//
+// Axis convention (the reference's): x = row index i (down), y = column index j (right),
+// images are row-major im[i*w + j].
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "sift_dev.h"
+#include "sift_launch.h"
+
+#define SA_PI 3.14159265358979323846
+#define SA_SQRT2 1.41421356237309504880
+
+// ------------------------------------------------------------------ helpers --
+
+// Half-sample symmetric extension with period 2l (lib_discrete.c:243-249), made total
+// for any i.
+__device__ __forceinline__ int mirror_idx(int i, int l)
+{
+    if ((unsigned)i < (unsigned)l) return i;
+    int ll = 2 * l;
+    i %= ll;
+    if (i < 0) i += ll;
+    if (i > l - 1) i = ll - 1 - i;
+    return i;
+}
+
+// lane i receives the value of lane i-1 / i+1 of the wave (edge lanes receive 0).
+__device__ __forceinline__ float lane_prev(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    unsigned lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ------------------------------------------------------- bilinear oversample --
+// lib_discrete.c:207-237.  One thread per output sample.
+__global__ void __launch_bounds__(256)
+k_oversample(const float* __restrict__ in, int wi, int hi, long long s_in,
+             float* __restrict__ out, int wo, int ho, long long s_out, float delta)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= wo) return;
+    const float* src = in + (long long)blockIdx.z * s_in;
+    float x = i * delta, y = j * delta;
+    int im = (int)x, jm = (int)y;
+    int ip = im + 1, jp = jm + 1;
+    if (ip >= hi) ip = 2 * hi - 1 - ip;
+    if (im >= hi) im = 2 * hi - 1 - im;
+    if (jp >= wi) jp = 2 * wi - 1 - jp;
+    if (jm >= wi) jm = 2 * wi - 1 - jm;
+    const float fx = x - floorf(x);
+    const float fy = y - floorf(y);
+    const float a = src[(long long)ip * wi + jp], b = src[(long long)ip * wi + jm];
+    const float c = src[(long long)im * wi + jp], d = src[(long long)im * wi + jm];
+    const float top = __fadd_rn(__fmul_rn(fy, a), __fmul_rn(1 - fy, b));
+    const float bot = __fadd_rn(__fmul_rn(fy, c), __fmul_rn(1 - fy, d));
+    out[(long long)blockIdx.z * s_out + (long long)i * wo + j] =
+        __fadd_rn(__fmul_rn(fx, top), __fmul_rn(1 - fx, bot));
+}
+
+// lib_discrete.c:180-191
+__global__ void __launch_bounds__(256)
+k_subsample2(const float* __restrict__ in, int wi, long long s_in,
+             float* __restrict__ out, int wo, int ho, long long s_out)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= wo) return;
+    out[(long long)blockIdx.z * s_out + (long long)i * wo + j] =
+        in[(long long)blockIdx.z * s_in + (long long)(2 * i) * wi + 2 * j];
+}
+
+// ------------------------------------------------------------ Gaussian blur --
+// lib_discrete.c:278-308: pass 1 along i (column direction) into a temporary, pass 2 along
+// j.  Per output:  sum = centre*g0;  sum += g[k]*(left_k + right_k)  for k = 1..R.
+
+// Pass 1.  One thread per column; it walks down a strip of rows keeping the 2R+G most
+// recent samples in registers, so every input sample is loaded once per strip and lanes of
+// a wave read consecutive addresses.  No LDS.
+template <int R>
+__global__ void __launch_bounds__(256)
+k_blur_v(const float* __restrict__ in, float* __restrict__ out, int w, int h,
+         long long s_in, long long s_out, SaTaps tp, int rows_per_block)
+{
+    constexpr int G = 8;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= w) return;
+    const float* src = in + (long long)blockIdx.z * s_in + j;
+    float* dst = out + (long long)blockIdx.z * s_out + j;
+    const int i0 = blockIdx.y * rows_per_block;
+    const int i1 = min(i0 + rows_per_block, h);
+
+    float win[G + 2 * R];
+    float nx[G];
+#pragma unroll
+    for (int t = 0; t < 2 * R; ++t) win[t] = src[(long long)mirror_idx(i0 - R + t, h) * w];
+#pragma unroll
+    for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(i0 + R + g, h) * w];
+
+    for (int ii = i0; ii < i1; ii += G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
+        if (ii + G < i1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(ii + G + R + g, h) * w];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = __fmul_rn(win[g + R], tp.g[0]);
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+                s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[g + R - k], win[g + R + k])));
+            if (ii + g < i1) dst[(long long)(ii + g) * w] = s;
+        }
+#pragma unroll
+        for (int t = 0; t < 2 * R; ++t) win[t] = win[t + G];
+    }
+}
+
+// Pass 2 with the DoG epilogue.  A wave stages one row segment of 256+2*16 samples in
+// LDS, every lane then produces 4 adjacent outputs from a 36-sample register window
+// (9 aligned 16-byte LDS reads).  Writes gss[s] and, if `dog` is given,
+// dog[s-1] = gss[s] - gss[s-1]  (lib_sift_anatomy.c:169-186).
+template <int R>
+__global__ void __launch_bounds__(256)
+k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
+         float* __restrict__ out, float* __restrict__ dog, int w, int h,
+         long long s_tmp, long long s_prev, long long s_out, long long s_dog,
+         SaTaps tp, int rows_per_wave)
+{
+    constexpr int RP = 16, TW = 256, LW = TW + 2 * RP;
+    __shared__ __attribute__((aligned(16))) float lds[4][LW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = blockIdx.x * TW;
+    const int row0 = (blockIdx.y * 4 + wave) * rows_per_wave;
+    const long long b = blockIdx.z;
+    const float* src = tmp + b * s_tmp;
+    const bool fast = ((w & 3) == 0) && (x0 - RP >= 0) && (x0 + TW + RP <= w);
+    float* row_lds = lds[wave];
+
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int row = row0 + rr;
+        const bool active = row < h;
+        if (active) {
+            const float* srow = src + (long long)row * w;
+            if (fast) {
+                const float4 a = *reinterpret_cast<const float4*>(srow + x0 - RP + 4 * lane);
+                *reinterpret_cast<float4*>(row_lds + 4 * lane) = a;
+                if (lane < (LW - TW) / 4) {
+                    const float4 c = *reinterpret_cast<const float4*>(srow + x0 - RP + TW + 4 * lane);
+                    *reinterpret_cast<float4*>(row_lds + TW + 4 * lane) = c;
+                }
+            } else {
+                for (int t = lane; t < LW; t += 64) row_lds[t] = srow[mirror_idx(x0 - RP + t, w)];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            float win[4 + 2 * RP];
+#pragma unroll
+            for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(row_lds + 4 * lane + 4 * q);
+                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
+            }
+            float o4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = __fmul_rn(win[RP + q], tp.g[0]);
+#pragma unroll
+                for (int k = 1; k <= R; ++k)
+                    s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[RP + q - k], win[RP + q + k])));
+                o4[q] = s;
+            }
+            const int x = x0 + 4 * lane;
+            const long long off = (long long)row * w + x;
+            if (fast) {
+                *reinterpret_cast<float4*>(out + b * s_out + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                if (dog) {
+                    const float4 p = *reinterpret_cast<const float4*>(prev + b * s_prev + off);
+                    *reinterpret_cast<float4*>(dog + b * s_dog + off) =
+                        make_float4(__fsub_rn(o4[0], p.x), __fsub_rn(o4[1], p.y),
+                                    __fsub_rn(o4[2], p.z), __fsub_rn(o4[3], p.w));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (x + q < w) {
+                        out[b * s_out + off + q] = o4[q];
+                        if (dog) dog[b * s_dog + off + q] = __fsub_rn(o4[q], prev[b * s_prev + off + q]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Any radius (taps in global memory); one thread per output sample.  Only used for
+// radii above SA_MAX_RADIUS_FAST, i.e. non-default parameters.
+__global__ void __launch_bounds__(256)
+k_blur_v_any(const float* __restrict__ in, float* __restrict__ out, int w, int h,
+             long long s_in, long long s_out, const float* __restrict__ taps, int R)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= w) return;
+    const float* src = in + (long long)blockIdx.z * s_in + j;
+    float s = __fmul_rn(src[(long long)i * w], taps[0]);
+    for (int k = 1; k <= R; ++k)
+        s = __fadd_rn(s, __fmul_rn(taps[k], __fadd_rn(src[(long long)mirror_idx(i - k, h) * w],
+                                                     src[(long long)mirror_idx(i + k, h) * w])));
+    out[(long long)blockIdx.z * s_out + (long long)i * w + j] = s;
+}
+
+__global__ void __launch_bounds__(256)
+k_blur_h_any(const float* __restrict__ tmp, const float* __restrict__ prev,
+             float* __restrict__ out, float* __restrict__ dog, int w, int h,
+             long long s_tmp, long long s_prev, long long s_out, long long s_dog,
+             const float* __restrict__ taps, int R)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= w) return;
+    const long long b = blockIdx.z;
+    const float* srow = tmp + b * s_tmp + (long long)i * w;
+    float s = __fmul_rn(srow[j], taps[0]);
+    for (int k = 1; k <= R; ++k)
+        s = __fadd_rn(s, __fmul_rn(taps[k], __fadd_rn(srow[mirror_idx(j - k, w)], srow[mirror_idx(j + k, w)])));
+    const long long off = (long long)i * w + j;
+    out[b * s_out + off] = s;
+    if (dog) dog[b * s_dog + off] = __fsub_rn(s, prev[b * s_prev + off]);
+}
+
+// dog[s] = gss[s+1] - gss[s] over a whole stack (used by the stand-alone
+// scalespace_compute entry point and when the blur ran without the epilogue).
+__global__ void __launch_bounds__(256)
+k_sub(const float* __restrict__ a, const float* __restrict__ bsrc, float* __restrict__ out,
+      long long n, long long s_a, long long s_b, long long s_out)
+{
+    const long long z = blockIdx.z;
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < n; p += (long long)gridDim.x * 256)
+        out[z * s_out + p] = __fsub_rn(a[z * s_a + p], bsrc[z * s_b + p]);
+}
+
+// Gradient images (lib_discrete.c:87-130), only materialised for the compatibility API.
+__device__ __forceinline__ float grad_i(const float* im, int w, int h, int i, int j)
+{
+    if (i == 0) return __fsub_rn(im[(long long)w + j], im[j]);
+    if (i == h - 1) return __fsub_rn(im[(long long)(h - 1) * w + j], im[(long long)(h - 2) * w + j]);
+    return __fmul_rn(__fsub_rn(im[(long long)(i + 1) * w + j], im[(long long)(i - 1) * w + j]), 0.5f);
+}
+__device__ __forceinline__ float grad_j(const float* im, int w, int h, int i, int j)
+{
+    (void)h;
+    const float* r = im + (long long)i * w;
+    if (j == 0) return __fsub_rn(r[1], r[0]);
+    if (j == w - 1) return __fsub_rn(r[w - 1], r[w - 2]);
+    return __fmul_rn(__fsub_rn(r[j + 1], r[j - 1]), 0.5f);
+}
+
+__global__ void __launch_bounds__(256)
+k_gradient(const float* __restrict__ im, float* __restrict__ gi, float* __restrict__ gj,
+           int w, int h, int n_img)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= w) return;
+    const long long off = (long long)blockIdx.z * w * h;
+    gi[off + (long long)i * w + j] = grad_i(im + off, w, h, i, j);
+    gj[off + (long long)i * w + j] = grad_j(im + off, w, h, i, j);
+    (void)n_img;
+}
+
+// ------------------------------------------------------------ extrema scan --
+// lib_sift_anatomy.c:240-313 fused with the first contrast test (:326-338).
+// A wave owns 62 output columns (lanes 1..62; lanes 0 and 63 only supply neighbours) and
+// walks down a strip of rows for all scales at once.  Per DoG image and row it keeps the
+// horizontal 3-max / 3-min, so the 26-neighbour test of a sample is a handful of max3/min3.
+// Hits are compacted with a wave ballot and one atomic per wave.
+template <int NDOG>
+struct ExtWin {
+    float M3[NDOG][3], N3[NDOG][3];          // max / min of (left, centre, right), 3 rows
+    float C[NDOG - 2][3], EM[NDOG - 2][3], Em[NDOG - 2][3];  // centre, max/min of (left,right)
+};
+
+template <int NDOG, int SLOT>
+__device__ __forceinline__ void ext_load(ExtWin<NDOG>& W, const float* __restrict__ base,
+                                         long long img_n, long long off)
+{
+#pragma unroll
+    for (int d = 0; d < NDOG; ++d) {
+        const float v = base[d * img_n + off];
+        const float l = lane_prev(v), r = lane_next(v);
+        W.M3[d][SLOT] = max3f(l, v, r);
+        W.N3[d][SLOT] = min3f(l, v, r);
+        if (d >= 1 && d <= NDOG - 2) {
+            W.C[d - 1][SLOT] = v;
+            W.EM[d - 1][SLOT] = fmaxf(l, r);
+            W.Em[d - 1][SLOT] = fminf(l, r);
+        }
+    }
+}
+
+template <int NDOG, int TOP, int MID, int BOT>
+__device__ __forceinline__ void ext_eval(const ExtWin<NDOG>& W, bool lane_ok, int o, int i, int j,
+                                         float thr_pre, int emit_all,
+                                         unsigned long long* __restrict__ ckey, float* __restrict__ cval,
+                                         int* __restrict__ cnt, int cap, int& n_ext)
+{
+    float colM[NDOG], colm[NDOG];
+#pragma unroll
+    for (int d = 0; d < NDOG; ++d) {
+        colM[d] = max3f(W.M3[d][TOP], W.M3[d][MID], W.M3[d][BOT]);
+        colm[d] = min3f(W.N3[d][TOP], W.N3[d][MID], W.N3[d][BOT]);
+    }
+#pragma unroll
+    for (int s = 1; s <= NDOG - 2; ++s) {
+        const float c = W.C[s - 1][MID];
+        const float nbM = max3f(colM[s - 1], colM[s + 1], max3f(W.M3[s][TOP], W.M3[s][BOT], W.EM[s - 1][MID]));
+        const float nbm = min3f(colm[s - 1], colm[s + 1], min3f(W.N3[s][TOP], W.N3[s][BOT], W.Em[s - 1][MID]));
+        const bool ext = lane_ok && (nbM < c || nbm > c);
+        const unsigned long long mA = __ballot(ext);
+        if (mA) {
+            n_ext += __popcll(mA);
+            const bool keep = ext && (emit_all || fabsf(c) > thr_pre);
+            const unsigned long long mK = __ballot(keep);
+            if (mK) {
+                int base = 0;
+                if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)mK) - 1)
+                    base = atomicAdd(&cnt[SA_CNT_CAND], __popcll(mK));
+                base = __shfl(base, __ffsll((long long)mK) - 1);
+                if (keep) {
+                    const int idx = base + __popcll(mK & lanemask_lt());
+                    if (idx < cap) {
+                        ckey[idx] = sa_pack_key(o, s, i, j);
+                        cval[idx] = c;
+                    } else {
+                        cnt[SA_CNT_OVERFLOW] = 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NDOG>
+__global__ void __launch_bounds__(256)
+k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
+          float thr_pre, int emit_all, int rows_per_wave,
+          unsigned long long* __restrict__ ckey, float* __restrict__ cval,
+          int* __restrict__ counters, int cap)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * 4 + wave;
+    const int jraw = seg * 62 + lane;                // lane 1 of seg 0 is column 1
+    const long long b = blockIdx.z;
+    const int ibeg = blockIdx.y * rows_per_wave + 1;  // first output row of the strip
+    const int iend = min(ibeg + rows_per_wave, h - 1);  // one past the last output row
+    if (seg * 62 + 1 > w - 2 || ibeg >= iend) return;  // wave-uniform
+    const int j = min(jraw, w - 1);
+    const bool lane_ok = lane >= 1 && lane <= 62 && jraw <= w - 2;
+    const float* base = dog + b * s_dog + j;
+    const long long img_n = (long long)w * h;
+    unsigned long long* kb = ckey + b * cap;
+    float* vb = cval + b * cap;
+    int* cnt = counters + b * SA_CNT_STRIDE;
+
+    ExtWin<NDOG> W;
+    int n_ext = 0;
+    ext_load<NDOG, 0>(W, base, img_n, (long long)(ibeg - 1) * w);
+    ext_load<NDOG, 1>(W, base, img_n, (long long)ibeg * w);
+    int i = ibeg;
+    while (true) {
+        ext_load<NDOG, 2>(W, base, img_n, (long long)(i + 1) * w);
+        ext_eval<NDOG, 0, 1, 2>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+        ext_load<NDOG, 0>(W, base, img_n, (long long)(i + 1) * w);
+        ext_eval<NDOG, 1, 2, 0>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+        ext_load<NDOG, 1>(W, base, img_n, (long long)(i + 1) * w);
+        ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+    }
+    if (lane == 0 && n_ext) {
+        atomicAdd(&cnt[SA_CNT_EXT_OCT + o], n_ext);
+        atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_A], n_ext);
+    }
+}
+
+// ------------------------------------------------- refinement and filters --
+// lib_sift_anatomy.c:358-405 (quadratic fit), :426-505 (iteration), :326-338 (contrast),
+// :525-575 (edge), :685-703 (border).  One thread per candidate.
+__device__ __forceinline__ void taylor3d(const float* __restrict__ st, int w, int h, int i, int j, int s,
+                                         float& oX, float& oY, float& oS, float& val)
+{
+    const long long n = (long long)w * h;
+#define D(ss, ii, jj) st[(long long)(ss) * n + (long long)(ii) * w + (jj)]
+    const float c = D(s, i, j);
+    const float c2 = __fmul_rn(2.f, c);
+    const float hXX = __fsub_rn(__fadd_rn(D(s, i - 1, j), D(s, i + 1, j)), c2);
+    const float hYY = __fsub_rn(__fadd_rn(D(s, i, j + 1), D(s, i, j - 1)), c2);
+    const float hSS = __fsub_rn(__fadd_rn(D(s + 1, i, j), D(s - 1, i, j)), c2);
+    const float hXY = __fmul_rn(0.25f, __fsub_rn(__fsub_rn(D(s, i + 1, j + 1), D(s, i + 1, j - 1)),
+                                                __fsub_rn(D(s, i - 1, j + 1), D(s, i - 1, j - 1))));
+    const float hXS = __fmul_rn(0.25f, __fsub_rn(__fsub_rn(D(s + 1, i + 1, j), D(s + 1, i - 1, j)),
+                                                __fsub_rn(D(s - 1, i + 1, j), D(s - 1, i - 1, j))));
+    const float hYS = __fmul_rn(0.25f, __fsub_rn(__fsub_rn(D(s + 1, i, j + 1), D(s + 1, i, j - 1)),
+                                                __fsub_rn(D(s - 1, i, j + 1), D(s - 1, i, j - 1))));
+    const float gX = __fmul_rn(0.5f, __fsub_rn(D(s, i + 1, j), D(s, i - 1, j)));
+    const float gY = __fmul_rn(0.5f, __fsub_rn(D(s, i, j + 1), D(s, i, j - 1)));
+    const float gS = __fmul_rn(0.5f, __fsub_rn(D(s + 1, i, j), D(s - 1, i, j)));
+#undef D
+    // det = hXX*hYY*hSS - hXX*hYS*hYS - hXY*hXY*hSS + 2*hXY*hXS*hYS - hXS*hXS*hYY
+    float det = __fmul_rn(__fmul_rn(hXX, hYY), hSS);
+    det = __fsub_rn(det, __fmul_rn(__fmul_rn(hXX, hYS), hYS));
+    det = __fsub_rn(det, __fmul_rn(__fmul_rn(hXY, hXY), hSS));
+    det = __fadd_rn(det, __fmul_rn(__fmul_rn(__fmul_rn(2.f, hXY), hXS), hYS));
+    det = __fsub_rn(det, __fmul_rn(__fmul_rn(hXS, hXS), hYY));
+    const float aa = __fdiv_rn(__fsub_rn(__fmul_rn(hYY, hSS), __fmul_rn(hYS, hYS)), det);
+    const float ab = __fdiv_rn(__fsub_rn(__fmul_rn(hXS, hYS), __fmul_rn(hXY, hSS)), det);
+    const float ac = __fdiv_rn(__fsub_rn(__fmul_rn(hXY, hYS), __fmul_rn(hXS, hYY)), det);
+    const float bb = __fdiv_rn(__fsub_rn(__fmul_rn(hXX, hSS), __fmul_rn(hXS, hXS)), det);
+    const float bc = __fdiv_rn(__fsub_rn(__fmul_rn(hXY, hXS), __fmul_rn(hXX, hYS)), det);
+    const float cc = __fdiv_rn(__fsub_rn(__fmul_rn(hXX, hYY), __fmul_rn(hXY, hXY)), det);
+    oX = __fsub_rn(__fsub_rn(__fmul_rn(-aa, gX), __fmul_rn(ab, gY)), __fmul_rn(ac, gS));
+    oY = __fsub_rn(__fsub_rn(__fmul_rn(-ab, gX), __fmul_rn(bb, gY)), __fmul_rn(bc, gS));
+    oS = __fsub_rn(__fsub_rn(__fmul_rn(-ac, gX), __fmul_rn(bc, gY)), __fmul_rn(cc, gS));
+    const float oV = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(__fmul_rn(gX, oX), __fmul_rn(gY, oY)), __fmul_rn(gS, oS)));
+    val = __fadd_rn(c, oV);
+}
+
+__global__ void __launch_bounds__(256)
+k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
+         const float* __restrict__ cval, int* __restrict__ counters, int cap,
+         SaKey* __restrict__ ref, int* __restrict__ stage)
+{
+    const long long b = blockIdx.y;
+    int* cnt = counters + b * SA_CNT_STRIDE;
+    const int n = min(cnt[SA_CNT_CAND], cap);
+    int nB = 0, nC = 0, nD = 0, nE = 0, nF = 0;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < n; c += gridDim.x * 256) {
+        const unsigned long long key = ckey[b * cap + c];
+        const int o = (int)(key >> 44), s0 = (int)((key >> 40) & 0xf);
+        const int i0 = (int)((key >> 20) & 0xfffff), j0 = (int)(key & 0xfffff);
+        const SaOctave& oc = P.oct[o];
+        const int w = oc.w, h = oc.h, ns = P.n_sca - 1;
+        const float delta = oc.delta;
+        const float* st = oc.dog + b * oc.dog_stride;
+        float val = cval[b * cap + c];
+        SaKey k;
+        k.o = o; k.s = s0; k.i = i0; k.j = j0;
+        k.x = __fmul_rn(delta, (float)i0);
+        k.y = __fmul_rn(delta, (float)j0);
+        k.sigma = oc.sigmas[s0];
+        k.theta = 0.f; k.val = val; k.edge = 0.f;
+        int stg = SA_ST_A;
+        if (fabsf(val) > sc.thr_pre) {
+            stg = SA_ST_B; ++nB;
+            int ic = i0, jc = j0, scur = s0, it = 0;
+            bool conv = false;
+            float oX = 0.f, oY = 0.f, oS = 0.f;
+            while (it < sc.itermax) {
+                if (0 < ic && ic < h - 1 && 0 < jc && jc < w - 1) {
+                    taylor3d(st, w, h, ic, jc, scur, oX, oY, oS, val);
+                } else {
+                    oX = oY = oS = 5.0f;
+                }
+                if (fabsf(oX) < 0.6f && fabsf(oY) < 0.6f && fabsf(oS) < 0.6f) { conv = true; break; }
+                if (oX > +0.6f && ic + 1 < h - 1) ic += 1;
+                if (oX < -0.6f && ic - 1 > 0) ic -= 1;
+                if (oY > +0.6f && jc + 1 < w - 1) jc += 1;
+                if (oY < -0.6f && jc - 1 > 0) jc -= 1;
+                if (oS > +0.6f && scur + 1 < ns - 1) scur += 1;
+                if (oS < -0.6f && scur - 1 > 0) scur -= 1;
+                ++it;
+            }
+            if (conv) {
+                stg = SA_ST_C; ++nC;
+                k.x = __fmul_rn(__fadd_rn((float)ic, oX), delta);
+                k.y = __fmul_rn(__fadd_rn((float)jc, oY), delta);
+                k.i = ic; k.j = jc; k.s = scur;
+                k.sigma = (float)((double)oc.sigmas[scur] * pow((double)sc.sigma_ratio, (double)oS));
+                k.val = val;
+                if (fabsf(val) > sc.thr) {
+                    stg = SA_ST_D; ++nD;
+                    const float* im = st + (long long)scur * w * h;
+                    const float c0 = im[(long long)ic * w + jc];
+                    const float c2 = __fmul_rn(2.f, c0);
+                    const float hXX = __fsub_rn(__fadd_rn(im[(long long)(ic - 1) * w + jc], im[(long long)(ic + 1) * w + jc]), c2);
+                    const float hYY = __fsub_rn(__fadd_rn(im[(long long)ic * w + jc + 1], im[(long long)ic * w + jc - 1]), c2);
+                    const float hXY = __fmul_rn(0.25f, __fsub_rn(
+                        __fsub_rn(im[(long long)(ic + 1) * w + jc + 1], im[(long long)(ic + 1) * w + jc - 1]),
+                        __fsub_rn(im[(long long)(ic - 1) * w + jc + 1], im[(long long)(ic - 1) * w + jc - 1])));
+                    const float tr = __fadd_rn(hXX, hYY);
+                    k.edge = __fdiv_rn(__fmul_rn(tr, tr), __fsub_rn(__fmul_rn(hXX, hYY), __fmul_rn(hXY, hXY)));
+                    if (fabsf(k.edge) <= sc.thr_edge) {
+                        stg = SA_ST_E; ++nE;
+                        const float ls = k.sigma;  // lambda = 1
+                        const bool in = (__fsub_rn(k.x, ls) > 0.f) && (__fadd_rn(k.x, ls) < (float)P.im_h)
+                                     && (__fsub_rn(k.y, ls) > 0.f) && (__fadd_rn(k.y, ls) < (float)P.im_w);
+                        if (in) { stg = SA_ST_F; ++nF; }
+                    }
+                }
+            }
+        }
+        ref[b * cap + c] = k;
+        stage[b * cap + c] = stg;
+    }
+    // stage sizes (integer atomics: order independent)
+    if (nB) atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_B], nB);
+    if (nC) atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_C], nC);
+    if (nD) atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_D], nD);
+    if (nE) atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_E], nE);
+    if (nF) atomicAdd(&cnt[SA_CNT_STAGE + SA_ST_F], nF);
+}
+
+// ----------------------------------------------------- canonical ordering --
+// The reference lists are in lexicographic (o,s,i,j) order of the discrete extremum that
+// seeded each keypoint.  Survivors of all filters are few, so each one simply counts how
+// many surviving seeds precede it (keys are unique) and stores itself at that rank.
+__global__ void __launch_bounds__(256)
+k_rank(const unsigned long long* __restrict__ ckey, const int* __restrict__ stage,
+       int* __restrict__ counters, int cap, int* __restrict__ flist, int fcap)
+{
+    __shared__ unsigned long long tile[1024];
+    const long long b = blockIdx.y;
+    int* cnt = counters + b * SA_CNT_STRIDE;
+    const int n = min(cnt[SA_CNT_CAND], cap);
+    for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+        const int c = base + threadIdx.x;
+        const bool mine = c < n && stage[b * cap + c] == SA_ST_F;
+        const unsigned long long key = mine ? ckey[b * cap + c] : 0ull;
+        int rank = 0;
+        for (int t0 = 0; t0 < n; t0 += 1024) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < 1024; t += 256) {
+                const int cc = t0 + t;
+                tile[t] = (cc < n && stage[b * cap + cc] == SA_ST_F) ? ckey[b * cap + cc] : ~0ull;
+            }
+            __syncthreads();
+            const int lim = min(1024, n - t0);
+            if (mine)
+                for (int t = 0; t < lim; ++t) rank += tile[t] < key;
+        }
+        if (mine) {
+            if (rank < fcap) flist[b * fcap + rank] = c;
+            else cnt[SA_CNT_OVERFLOW] = 1;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[SA_CNT_NF] = min(cnt[SA_CNT_STAGE + SA_ST_F], fcap);
+}
+
+// --------------------------------------------------- orientation histogram --
+__device__ __forceinline__ float modulus_f(float x, float y)   // lib_util.c:187-198
+{
+    float z = x;
+    int n;
+    if (z < 0) {
+        n = (int)__fdiv_rn(-z, y) + 1;
+        z = __fadd_rn(z, __fmul_rn((float)n, y));
+    }
+    n = (int)__fdiv_rn(z, y);
+    z = __fsub_rn(z, __fmul_rn((float)n, y));
+    return z;
+}
+
+__device__ __forceinline__ float bin_to_ori(float bin, int nbins)   // lib_description.c:88-94
+{
+    float ori = (float)(((double)bin + 0.5) * 2 * SA_PI / (double)(float)nbins);
+    if ((double)ori > SA_PI) ori = (float)((double)ori - 2 * SA_PI);
+    return ori;
+}
+
+// lib_description.c:122-169 (accumulation), :406-423 (smoothing), :201-227 (peaks),
+// driver loops lib_sift_anatomy.c:599-681.  One wave per keypoint; lane p of a chunk handles
+// the p-th sample of the patch in raster order, lane b (< n_bins) owns histogram bin b and
+// adds the chunk's contributions to it in sample order.
+// mode 0: every peak above t*max becomes a keypoint; mode 1: only the global maximum.
+__global__ void __launch_bounds__(64)
+k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ index,
+              const int* __restrict__ counters, int cnt_slot, int kcap, int icap, int mode,
+              int* __restrict__ ori_n, float* __restrict__ ori_theta, float* __restrict__ ori_hist)
+{
+    const int lane = threadIdx.x;
+    const long long b = blockIdx.y;
+    const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], icap);
+    const int nbins = sc.n_bins;
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        const int src = index ? index[b * icap + q] : q;
+        const SaKey key = keys[b * kcap + src];
+        const SaOctave& oc = P.oct[key.o];
+        const int w = oc.w, h = oc.h;
+        const float* im = oc.gss + b * oc.gss_stride + (long long)key.s * w * h;
+        const float xk = __fdiv_rn(key.x, oc.delta), yk = __fdiv_rn(key.y, oc.delta);
+        const float sk = __fdiv_rn(key.sigma, oc.delta);
+        const float R = __fmul_rn(__fmul_rn(3.f, sc.lambda_ori), sk);
+        const int i0 = max(0, (int)((double)__fsub_rn(xk, R) + 0.5));
+        const int j0 = max(0, (int)((double)__fsub_rn(yk, R) + 0.5));
+        const int i1 = min((int)((double)__fadd_rn(xk, R) + 0.5), h - 1);
+        const int j1 = min((int)((double)__fadd_rn(yk, R) + 0.5), w - 1);
+        const int nw = j1 - j0 + 1, nh = i1 - i0 + 1;
+        const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
+        const float denom = __fmul_rn(__fmul_rn(2.f, sc.lambda_ori), sc.lambda_ori);
+        float hb = 0.f;
+        for (int p0 = 0; p0 < npix; p0 += 64) {
+            const int p = p0 + lane;
+            int bin = -1;
+            float M = 0.f;
+            if (p < npix) {
+                const int si = i0 + p / nw, sj = j0 + p % nw;
+                const float sX = __fdiv_rn(__fsub_rn((float)si, xk), sk);
+                const float sY = __fdiv_rn(__fsub_rn((float)sj, yk), sk);
+                const float dx = grad_i(im, w, h, si, sj);
+                const float dy = grad_j(im, w, h, si, sj);
+                float ori = modulus_f((float)atan2((double)dy, (double)dx), (float)(2 * SA_PI));
+                const float r2 = __fadd_rn(__fmul_rn(sX, sX), __fmul_rn(sY, sY));
+                M = (float)(hypot((double)dx, (double)dy) * exp((double)__fdiv_rn(-r2, denom)));
+                if (ori < 0) ori = (float)((double)ori + 2 * SA_PI);
+                bin = (int)((double)ori / (2 * SA_PI) * nbins + 0.5) % nbins;
+            }
+            const int lim = min(64, npix - p0);
+#pragma unroll 8
+            for (int e = 0; e < lim; ++e) {
+                const int be = __shfl(bin, e);
+                const float Me = __shfl(M, e);
+                if (be == lane) hb = __fadd_rn(hb, Me);
+            }
+        }
+        // six circular box passes
+        for (int it = 0; it < 6; ++it) {
+            const float pv = __shfl(hb, (lane - 1 + nbins) % nbins);
+            const float nv = __shfl(hb, (lane + 1) % nbins);
+            hb = (float)((double)__fadd_rn(__fadd_rn(pv, hb), nv) / 3.);
+        }
+        float mx = lane < nbins ? hb : -3.402823466e+38f;
+        for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+        const float h1 = __shfl(hb, (lane - 1 + nbins) % nbins);
+        const float h3 = __shfl(hb, (lane + 1) % nbins);
+        bool peak;
+        if (mode == 0) {
+            peak = lane < nbins && hb > __fmul_rn(sc.t_peak, mx) && hb > h1 && hb > h3;
+        } else {
+            const unsigned long long ismax = __ballot(lane < nbins && hb == mx);
+            peak = lane == __ffsll((long long)ismax) - 1;   // first bin holding the maximum
+        }
+        const unsigned long long pm = __ballot(peak);
+        const int np = min(__popcll(pm), SA_MAX_PEAKS);
+        if (peak) {
+            const int r = __popcll(pm & lanemask_lt());
+            if (r < SA_MAX_PEAKS) {
+                const float off = __fdiv_rn(__fsub_rn(h1, h3),
+                                            __fmul_rn(2.f, __fsub_rn(__fadd_rn(h1, h3), __fmul_rn(2.f, hb))));
+                ori_theta[(b * icap + q) * SA_MAX_PEAKS + r] = bin_to_ori(__fadd_rn((float)lane, off), nbins);
+            }
+        }
+        if (lane == 0) ori_n[b * icap + q] = np;
+        if (lane < nbins) ori_hist[(b * icap + q) * SA_MAX_BINS + lane] = hb;
+    }
+}
+
+// Exclusive scan of the per-keypoint orientation counts (in list order) and expansion
+// into the final keypoint list: one entry per (keypoint, orientation), orientations of a
+// keypoint adjacent and in ascending bin order (lib_sift_anatomy.c:636-640).
+__global__ void __launch_bounds__(1024)
+k_expand(const SaKey* __restrict__ keys, const int* __restrict__ index, int* __restrict__ counters,
+         int cnt_slot, int kcap, int icap, const int* __restrict__ ori_n,
+         const float* __restrict__ ori_theta, SaKey* __restrict__ out, int* __restrict__ out_src,
+         int ocap)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const long long b = blockIdx.x;
+    int* cnt = counters + b * SA_CNT_STRIDE;
+    const int n = min(cnt[cnt_slot], icap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int q = base + threadIdx.x;
+        const int v = q < n ? ori_n[b * icap + q] : 0;
+        int inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; ++k) woff += wsum[k];
+        int total = 0;
+        for (int k = 0; k < 16; ++k) total += wsum[k];
+        const int carry = carry_s;
+        const int off = carry + woff + inc - v;
+        if (q < n) {
+            const int src = index ? index[b * icap + q] : q;
+            SaKey k = keys[b * kcap + src];
+            for (int r = 0; r < v; ++r) {
+                if (off + r < ocap) {
+                    k.theta = ori_theta[(b * icap + q) * SA_MAX_PEAKS + r];
+                    out[b * ocap + off + r] = k;
+                    out_src[b * ocap + off + r] = q;
+                } else {
+                    cnt[SA_CNT_OVERFLOW] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cnt[SA_CNT_KEYS] = min(carry_s, ocap);
+}
+
+// ------------------------------------------------------------- descriptor --
+// lib_description.c:278-347 (accumulation) and :374-389 (clip, renormalise, quantise),
+// driver loop lib_sift_anatomy.c:724-765.  One 256-thread block per keypoint.  The patch is
+// swept in raster order, 256 samples at a time: every thread evaluates one sample (rotation,
+// gradient, Gaussian weight, continuous bin coordinates) into LDS, then thread t < n_descr,
+// which owns descriptor bin t, walks the chunk in order and adds what falls into its bin.
+__global__ void __launch_bounds__(256)
+k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
+             int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
+{
+    __shared__ float e_a[256], e_b[256], e_g[256];
+    __shared__ double e_m[256];
+    __shared__ float d_s[SA_MAX_DESCR];
+    __shared__ float norm_s;
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.y;
+    const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
+    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb;
+    const int bi = tid / (Nh * Nb), bj = (tid / Nb) % Nh, bk = tid % Nb;
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        const SaKey key = keys[b * kcap + q];
+        const SaOctave& oc = P.oct[key.o];
+        const int w = oc.w, h = oc.h;
+        const float* im = oc.gss + b * oc.gss_stride + (long long)key.s * w * h;
+        const float xk = __fdiv_rn(key.x, oc.delta), yk = __fdiv_rn(key.y, oc.delta);
+        const float sk = __fdiv_rn(key.sigma, oc.delta);
+        const float theta = key.theta;
+        const float R = __fmul_rn(__fmul_rn(__fadd_rn(1.f, __fdiv_rn(1.f, (float)Nh)), sc.lambda_descr), sk);
+        const float Rp = (float)(SA_SQRT2 * (double)R);
+        const int i0 = max(0, (int)((double)__fsub_rn(xk, Rp) + 0.5));
+        const int j0 = max(0, (int)((double)__fsub_rn(yk, Rp) + 0.5));
+        const int i1 = min((int)((double)__fadd_rn(xk, Rp) + 0.5), h - 1);
+        const int j1 = min((int)((double)__fadd_rn(yk, Rp) + 0.5), w - 1);
+        const int nw = j1 - j0, nh = i1 - i0;                 // upper bounds are exclusive
+        const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
+        const float ma = -theta;
+        const float ct = (float)cos((double)ma), st = (float)sin((double)ma);
+        const double tt = (double)__fmul_rn(sc.lambda_descr, sk);
+        const double two_t2 = 2 * tt * tt;
+        const float cell = __fdiv_rn(__fmul_rn(__fmul_rn(2.f, sc.lambda_descr), sk), (float)Nh);
+        const double half = ((double)Nh - 1.0) / 2.0;
+        float acc = 0.f;
+        for (int p0 = 0; p0 < npix; p0 += 256) {
+            const int p = p0 + tid;
+            float al = -100.f, be = -100.f, ga = 0.f;
+            double M = 0.0;
+            if (p < npix) {
+                const int si = i0 + p / nw, sj = j0 + p % nw;
+                const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
+                const float X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
+                const float Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
+                if (fmaxf(fabsf(X), fabsf(Y)) < R) {
+                    const double dx = (double)grad_i(im, w, h, si, sj);
+                    const double dy = (double)grad_j(im, w, h, si, sj);
+                    float ori = (float)(atan2(dy, dx) - (double)theta);
+                    ori = modulus_f(ori, (float)(2 * SA_PI));
+                    const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
+                    M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
+                    al = (float)((double)__fdiv_rn(X, cell) + half);
+                    be = (float)((double)__fdiv_rn(Y, cell) + half);
+                    ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                }
+            }
+            __syncthreads();
+            e_a[tid] = al; e_b[tid] = be; e_g[tid] = ga; e_m[tid] = M;
+            __syncthreads();
+            if (tid < nd) {
+                const int lim = min(256, npix - p0);
+                for (int e = 0; e < lim; ++e) {
+                    const float a = e_a[e];
+                    const float da = fabsf(__fsub_rn((float)bi, a));
+                    if (!(da < 1.f)) continue;
+                    const float db = fabsf(__fsub_rn((float)bj, e_b[e]));
+                    if (!(db < 1.f)) continue;
+                    const float g = e_g[e];
+                    const int gi = (int)g;
+                    const double gf = floor((double)g);
+                    const int k0 = (gi + Nb) % Nb, k1 = (gi + 1 + Nb) % Nb;
+                    const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
+                    if (bk == k0)
+                        acc = (float)((double)acc + (1. - ((double)g - gf)) * wa * wb * e_m[e]);
+                    if (bk == k1)
+                        acc = (float)((double)acc + (1.0 - (gf + 1 - (double)g)) * wa * wb * e_m[e]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < nd) d_s[tid] = acc;
+        __syncthreads();
+        // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
+        if (tid == 0) {
+            float l2 = 0.f;
+            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
+            norm_s = (float)sqrt((double)l2);
+        }
+        __syncthreads();
+        if (tid < nd) d_s[tid] = fminf(acc, __fmul_rn(0.2f, norm_s));
+        __syncthreads();
+        if (tid == 0) {
+            float l2 = 0.f;
+            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
+            norm_s = (float)sqrt((double)l2);
+        }
+        __syncthreads();
+        if (tid < nd) {
+            float v = (float)(int)((double)d_s[tid] * 512.0 / (double)norm_s);
+            v = v < 255.f ? v : 255.f;
+            if (out_descr) out_descr[(b * kcap + q) * SA_MAX_DESCR + tid] = v;
+            if (out_std && tid < 128) out_std[b * kcap + q].descriptor[tid] = (unsigned char)v;
+        }
+        if (out_std && tid == 0) {
+            SaStd* o = &out_std[b * kcap + q];
+            o->x = key.x; o->y = key.y; o->scale = key.sigma; o->orientation = key.theta;
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================ launchers ==
+#define HIPK(...) do { hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
+namespace sa {
+
+template <int R>
+static void blur_v_t(hipStream_t st, const BlurArgs& a)
+{
+    const int rows = 64;
+    dim3 grid((a.w + 255) / 256, (a.h + rows - 1) / rows, a.batch);
+    HIPK(k_blur_v<R>, grid, dim3(256), 0, st, a.in, a.tmp, a.w, a.h, a.s_in, a.s_tmp, a.taps, rows);
+}
+template <int R>
+static void blur_h_t(hipStream_t st, const BlurArgs& a)
+{
+    const int rpw = 8;
+    dim3 grid((a.w + 255) / 256, (a.h + 4 * rpw - 1) / (4 * rpw), a.batch);
+    HIPK(k_blur_h<R>, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
+         a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps, rpw);
+}
+
+#define SA_R_CASES(F) \
+    case 1: F(1); break; case 2: F(2); break; case 3: F(3); break; case 4: F(4); break; \
+    case 5: F(5); break; case 6: F(6); break; case 7: F(7); break; case 8: F(8); break; \
+    case 9: F(9); break; case 10: F(10); break; case 11: F(11); break; case 12: F(12); break; \
+    case 13: F(13); break; case 14: F(14); break; case 15: F(15); break; case 16: F(16); break;
+
+// pass 0: column pass (in -> tmp); pass 1: row pass (tmp -> out [, dog = out - in]).
+void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass)
+{
+    if (a.radius >= 1 && a.radius <= SA_MAX_RADIUS_FAST) {
+        if (pass == 0) {
+            switch (a.radius) {
+#define F(R) blur_v_t<R>(st, a)
+                SA_R_CASES(F)
+#undef F
+            }
+        } else {
+            switch (a.radius) {
+#define F(R) blur_h_t<R>(st, a)
+                SA_R_CASES(F)
+#undef F
+            }
+        }
+    } else {
+        dim3 grid((a.w + 255) / 256, a.h, a.batch);
+        if (pass == 0)
+            HIPK(k_blur_v_any, grid, dim3(256), 0, st, a.in, a.tmp, a.w, a.h, a.s_in, a.s_tmp, a.taps_dev, a.radius);
+        else
+            HIPK(k_blur_h_any, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
+                 a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps_dev, a.radius);
+    }
+}
+
+void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
+                       float* out, int wo, int ho, long long s_out, float delta, int batch)
+{
+    dim3 grid((wo + 255) / 256, ho, batch);
+    HIPK(k_oversample, grid, dim3(256), 0, st, in, wi, hi, s_in, out, wo, ho, s_out, delta);
+}
+
+void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,
+                      float* out, int wo, int ho, long long s_out, int batch)
+{
+    dim3 grid((wo + 255) / 256, ho, batch);
+    HIPK(k_subsample2, grid, dim3(256), 0, st, in, wi, s_in, out, wo, ho, s_out);
+}
+
+void launch_sub(hipStream_t st, const float* a, const float* b, float* out, long long n,
+                long long s_a, long long s_b, long long s_out, int batch)
+{
+    long long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    dim3 grid((unsigned)blocks, 1, batch);
+    HIPK(k_sub, grid, dim3(256), 0, st, a, b, out, n, s_a, s_b, s_out);
+}
+
+void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int w, int h, int n_img)
+{
+    dim3 grid((w + 255) / 256, h, n_img);
+    HIPK(k_gradient, grid, dim3(256), 0, st, im, gi, gj, w, h, n_img);
+}
+
+int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
+                   float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
+                   int* counters, int cap, int batch)
+{
+    if (w < 3 || h < 3) return 0;
+    const int rpw = 32;
+    const int nseg = (w - 2 + 61) / 62;
+    dim3 grid((nseg + 3) / 4, (h - 2 + rpw - 1) / rpw, batch);
+#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap)
+    switch (n_dog) {
+        case 3: EXT(3); break; case 4: EXT(4); break; case 5: EXT(5); break;
+        case 6: EXT(6); break; case 7: EXT(7); break; case 8: EXT(8); break;
+        case 9: EXT(9); break; case 10: EXT(10); break; case 11: EXT(11); break;
+        default: return -1;
+    }
+#undef EXT
+    return 0;
+}
+
+void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,
+                   const float* cval, int* counters, int cap, SaKey* ref, int* stage, int batch)
+{
+    HIPK(k_refine, dim3(64, batch), dim3(256), 0, st, P, sc, ckey, cval, counters, cap, ref, stage);
+}
+
+void launch_rank(hipStream_t st, const unsigned long long* ckey, const int* stage, int* counters, int cap,
+                 int* flist, int fcap, int batch)
+{
+    HIPK(k_rank, dim3(32, batch), dim3(256), 0, st, ckey, stage, counters, cap, flist, fcap);
+}
+
+void launch_orientation(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
+                        const int* index, const int* counters, int cnt_slot, int kcap, int icap, int mode,
+                        int* ori_n, float* ori_theta, float* ori_hist, int batch)
+{
+    HIPK(k_orientation, dim3(2048, batch), dim3(64), 0, st, P, sc, keys, index, counters, cnt_slot,
+         kcap, icap, mode, ori_n, ori_theta, ori_hist);
+}
+
+void launch_expand(hipStream_t st, const SaKey* keys, const int* index, int* counters, int cnt_slot,
+                   int kcap, int icap, const int* ori_n, const float* ori_theta, SaKey* out,
+                   int* out_src, int ocap, int batch)
+{
+    HIPK(k_expand, dim3(batch), dim3(1024), 0, st, keys, index, counters, cnt_slot, kcap, icap,
+         ori_n, ori_theta, out, out_src, ocap);
+}
+
+void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
+                       const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
+                       int batch)
+{
+    HIPK(k_descriptor, dim3(1024, batch), dim3(256), 0, st, P, sc, keys, counters, cnt_slot, kcap,
+         out_std, out_descr);
+}
+
+}  // namespace sa

@@ -1,0 +1,49 @@
+// Host-callable launch wrappers of the kernels in sift_kernels.hip (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sift_dev.h"
+
+struct sift_amd_ctx;
+
+namespace sa {
+
+struct BlurArgs {
+    const float* in;     // source images            [batch] stride s_in
+    float* tmp;          // column-pass result       [batch] stride s_tmp
+    float* out;          // blurred images           [batch] stride s_out
+    float* dog;          // optional: out - in       [batch] stride s_dog (nullptr = skip)
+    long long s_in, s_tmp, s_out, s_dog;
+    int w, h, batch;
+    int radius;
+    SaTaps taps;             // radius <= SA_MAX_RADIUS_FAST
+    const float* taps_dev;   // radius+1 taps in device memory (any radius)
+};
+
+void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
+void launch_blur_profiled(hipStream_t st, const BlurArgs& a, struct ::sift_amd_ctx* c, int octave);
+void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
+                       float* out, int wo, int ho, long long s_out, float delta, int batch);
+void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,
+                      float* out, int wo, int ho, long long s_out, int batch);
+void launch_sub(hipStream_t st, const float* a, const float* b, float* out, long long n,
+                long long s_a, long long s_b, long long s_out, int batch);
+void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int w, int h, int n_img);
+int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
+                   float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
+                   int* counters, int cap, int batch);
+void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,
+                   const float* cval, int* counters, int cap, SaKey* ref, int* stage, int batch);
+void launch_rank(hipStream_t st, const unsigned long long* ckey, const int* stage, int* counters, int cap,
+                 int* flist, int fcap, int batch);
+void launch_orientation(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
+                        const int* index, const int* counters, int cnt_slot, int kcap, int icap, int mode,
+                        int* ori_n, float* ori_theta, float* ori_hist, int batch);
+void launch_expand(hipStream_t st, const SaKey* keys, const int* index, int* counters, int cnt_slot,
+                   int kcap, int icap, const int* ori_n, const float* ori_theta, SaKey* out,
+                   int* out_src, int ocap, int batch);
+void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
+                       const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
+                       int batch);
+
+}  // namespace sa
