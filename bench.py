@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the SIFT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the whole pipeline (scale-space, DoG, extrema, refinement,
+orientation, descriptors, host gather of the keypoints) over one batch of synthetic
+1920x1080 images per GPU; the images are resident in HBM before the timed region starts.
+For N > 1 the driver launches one process per GPU with torch.distributed.run; images are
+sharded by rank with no collective on the data path (weak scaling: every GPU processes
+the same number of images per step).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W_IM, H_IM = 1920, 1080
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(n_cores):
+    """Times the CPU implementation on the host cores, one process per core, one 1080p image
+    each.  Uses the compiled reference (oracle/_ref) when present, else the oracle port.
+    Must run before this process touches the GPU (workers are forked)."""
+    import multiprocessing as mp
+    from oracle import refrun, pyoracle
+    kind = "reference" if refrun.have_ref() else "port"
+    if kind == "port":
+        pyoracle.build()
+    ctx = mp.get_context("fork")
+    t0 = time.time()
+    with ctx.Pool(n_cores) as pool:
+        nkeys = pool.map(_cpu_one, [(kind, 12345 + b) for b in range(n_cores)])
+    dt = time.time() - t0
+    return {"value": n_cores / dt, "unit": "images/s", "cores": n_cores, "kind": kind,
+            "sample": f"{n_cores} synthetic 1920x1080 S1 images (seeds 12345..{12345 + n_cores - 1}), "
+                      f"one process per core, sift_anatomy with default parameters, "
+                      f"{dt:.1f} s wall, image generation excluded from neither side",
+            "keypoints": int(sum(nkeys))}
+
+
+def _cpu_one(arg):
+    kind, seed = arg
+    from sift_amd import synth
+    img = synth.smooth(W_IM, H_IM, seed)
+    if kind == "reference":
+        from oracle import refrun
+        rec = refrun.run_sift_anatomy(refrun.ref_lib(), img, keep_ss=False)
+    else:
+        from oracle import pyoracle
+        rec = pyoracle.run(img, keep_ss=False)
+    return len(rec["keys"]["ints"])
+
+
+def load_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (profiles/), if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--kind", default="smooth", choices=["smooth", "white"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(one process per GPU)")
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu:
+        n_cores = min(16, len(os.sched_getaffinity(0)))
+        cpu = cpu_baseline(n_cores)
+
+    import numpy as np
+    import torch
+    import sift_amd
+    from sift_amd import api, synth
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    # shard of the synthetic batch owned by this rank: image b of rank r has seed 12345 + r*B + b
+    host = np.stack([synth.make(args.kind, W_IM, H_IM, seed=12345 + rank * B + b) for b in range(B)])
+    d_imgs = torch.from_numpy(host).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = sift_amd.Context(W_IM, H_IM, max_batch=B, device=local_rank)
+
+    def step():
+        ctx.detect_device(d_imgs.data_ptr(), B, stream)
+        return ctx.gather()          # host-side gather of this rank's keypoints
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable([api.K_BLUR_H])
+    ctx.profile_read(api.K_BLUR_H, -1, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        keys, counts = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable([])
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    nk = torch.tensor([float(counts.sum())], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nk, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        # dominant kernel: the row pass of the blur with the DoG epilogue, octave 0.
+        # Algorithmic bytes per launch: it reads the column-pass result (4 B/px) and the previous
+        # Gaussian image (4 B/px, for the DoG) and writes the new Gaussian image and the DoG image
+        # (4 B/px each) -> 16 B/px; the seed launch has no DoG -> 8 B/px.
+        n0 = ctx.dims[0][0] * ctx.dims[0][1]
+        ms, launches = ctx.profile_read(api.K_BLUR_H, 0)
+        per_step = ctx.n_sca                       # seed + (n_sca-1) steps in octave 0
+        bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))
+        steps_timed = launches / per_step if per_step else 0
+        achieved = (bytes_per_step * steps_timed) / (ms * 1e-3) / 1e9 if ms > 0 else None
+        traffic = load_traffic()
+        out = {
+            "metric": "1080p images/sec",
+            "value": total_images / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch of {B} synthetic 1920x1080 images per GPU per step "
+                            f"({args.kind} S{'1' if args.kind == 'smooth' else '2'}, seeds 12345+), "
+                            "sift_anatomy default parameters, inputs resident in HBM, "
+                            "keypoints gathered to host memory inside the timed region",
+                "image": "1920x1080",
+                "batch_per_gpu": B,
+                "octaves": ctx.n_oct,
+                "keypoints_per_image": float(nk.item()) / (B * world),
+                "sharding": "by image, no collective on the data path",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_blur_h (row pass + DoG epilogue), octave 0",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic.get("bytes_per_launch") if traffic else None,
+                "launches_timed": launches,
+                "avg_launch_ms": (ms / launches) if launches else None,
+                "algorithmic_bytes_per_launch": bytes_per_step / per_step,
+            },
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""The C-ABI library: loads without a GPU, exports every symbol declared in include/*.h,
+struct layouts match the reference, the numerically sensitive kernels hold no fused
+multiply-adds, and nothing silently falls back to the CPU."""
+import ctypes as C
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+import sift_amd
+from sift_amd import abi, api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    L = sift_amd.lib()
+    names = declared_functions()
+    assert "sift_anatomy" in names and "sift_amd_detect_device" in names and len(names) > 40
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_struct_layouts():
+    assert C.sizeof(abi.SiftParameters) == 56
+    assert C.sizeof(abi.Keypoint) == 72
+    assert abi.Keypoint.descr.offset == 48 and abi.Keypoint.orihist.offset == 64
+    assert C.sizeof(abi.SiftKeypoints) == 16
+    assert C.sizeof(abi.Octa) == 32 and C.sizeof(abi.SiftScalespace) == 808
+    assert C.sizeof(abi.SiftKeypointStd) == 144
+    assert api.KEY_DTYPE.itemsize == 40
+
+
+def test_default_parameters_and_containers_without_gpu():
+    L = sift_amd.lib()
+    p = L.sift_assign_default_parameters()
+    assert bytes(p.contents) == bytes(abi.SiftParameters.default())
+    C.CDLL(None).free(C.cast(p, C.c_void_p))
+    lst = L.sift_malloc_keypoints()
+    assert lst.contents.size == 0 and lst.contents.capacity == 100
+    for k in range(250):
+        key = L.sift_malloc_keypoint(8, 4, 36)
+        key.contents.x = k
+        L.sift_add_keypoint_to_list(key, lst)
+    assert lst.contents.size == 250 and lst.contents.capacity == 400
+    assert lst.contents.list[249].contents.x == 249.0
+    L.sift_free_keypoints(lst)
+    ss = L.sift_malloc_scalespace_lowe(3, 3, 64, 48, C.c_float(0.5), C.c_float(0.8))
+    oc = ss.contents.octaves[1].contents
+    assert (oc.w, oc.h, oc.nSca) == (64, 48, 6) and oc.delta == 1.0
+    dog = L.sift_malloc_scalespace_dog_from_scalespace(ss)
+    assert dog.contents.octaves[0].contents.nSca == 5
+    L.sift_free_scalespace(dog)
+    L.sift_free_scalespace(ss)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU the product path must fail loudly, not compute on the host."""
+    if sift_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(sift_amd.SiftAmdError):
+        sift_amd.Context(64, 48)
+
+
+def test_product_does_not_reference_the_oracle():
+    for path in glob.glob(os.path.join(ROOT, "sift_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".h", ".cpp")):
+            text = open(path).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle|oracle/|liboracle|pyoracle|refrun", text, re.M), \
+                f"{path} refers to the test oracle"
+
+
+def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
+    """Disassembles the gfx950 code object embedded in the shipped library."""
+    objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = str(tmp_path / "lib.so")
+    shutil.copy(api.LIB_PATH, so)
+    subprocess.check_call([objdump, "--offloading", so], stdout=subprocess.DEVNULL)
+    cos = glob.glob(so + ".*gfx950*")
+    assert cos, "no gfx950 code object in the library"
+    asm = "".join(subprocess.check_output([objdump, "-d", co]).decode() for co in cos)
+    current, bad, seen = None, {}, set()
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            current = m.group(1)
+            continue
+        if current and re.search(r"k_blur_[vh]|k_oversample|k_sub", current):
+            seen.add(current)
+            if re.search(r"\bv_(fma|fmac|mad|mac|pk_fma)_f32", line):
+                bad[current] = bad.get(current, 0) + 1
+    assert len(seen) >= 30, f"blur kernels not found in the disassembly ({len(seen)})"
+    assert not bad, f"fused multiply-adds in bit-exact kernels: {bad}"

@@ -1,0 +1,139 @@
+"""GPU: the remaining reference-named entry points (flat lib_sift.h API, description-only
+variants, stand-alone scale-space), called through ctypes exactly as C host code would."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import sift_amd
+from sift_amd import abi, api, synth
+from oracle import pyoracle, refrun
+
+from common import same_bits
+
+pytestmark = pytest.mark.gpu
+P = C.POINTER
+
+
+def _std_array(ptr, n):
+    out = np.zeros(n, abi.KEYPOINT_STD_DTYPE)
+    if n:
+        C.memmove(out.ctypes.data, ptr, n * 144)
+    return out
+
+
+def test_sift_compute_features_flat_api(hip):
+    img = synth.white(240, 180, 11)
+    want = pyoracle.run(img, keep_ss=False)["keys"]
+    got = api.sift_compute_features(img)
+    assert len(got) == len(want["ints"])
+    assert same_bits(np.stack([got["x"], got["y"], got["scale"], got["orientation"]], 1), want["flts"][:, :4])
+    assert np.array_equal(got["descriptor"], want["descr"].astype(np.uint8))
+
+
+def test_sift_compute_points_returns_unoriented_border_filtered_list(hip):
+    img = synth.white(240, 180, 12)
+    want = pyoracle.run(img, keep_ss=False)["stages"]["F"]
+    n = C.c_int()
+    p = hip.sift_compute_points(img.ctypes.data_as(abi.c_float_p), 240, 180, C.byref(n))
+    got = _std_array(p, n.value)
+    C.CDLL(None).free(C.cast(p, C.c_void_p))
+    assert n.value == len(want["ints"])
+    assert same_bits(np.stack([got["x"], got["y"], got["scale"]], 1), np.ascontiguousarray(want["flts"][:, :3]))
+    assert not got["orientation"].any() and not got["descriptor"].any()
+
+
+def test_without_description_variant(hip):
+    img = synth.white(200, 150, 13)
+    want = pyoracle.run(img)
+    kk = (P(abi.SiftKeypoints) * 5)(*[hip.sift_malloc_keypoints() for _ in range(5)])
+    ss = (P(abi.SiftScalespace) * 2)()
+    k = hip.sift_anatomy_without_description(img.ctypes.data_as(abi.c_float_p), 200, 150,
+                                             C.byref(abi.SiftParameters.default()), ss, kk)
+    res = abi.keypoints_to_numpy(k, with_descr=False)
+    assert np.array_equal(res["ints"], want["stages"]["F"]["ints"])
+    assert same_bits(np.ascontiguousarray(res["flts"][:, [0, 1, 2, 4, 5]]),
+                     np.ascontiguousarray(want["stages"]["F"]["flts"][:, [0, 1, 2, 4, 5]]))
+    for name, lst in zip("ABCDE", kk):
+        assert np.array_equal(abi.keypoints_to_numpy(lst, False)["ints"], want["stages"][name]["ints"])
+    dog = abi.scalespace_to_numpy(ss[1])
+    for o in range(len(dog)):
+        assert same_bits(dog[o]["stack"], want["dog"][o])
+    hip.sift_free_keypoints(k)
+    for lst in kk:
+        hip.sift_free_keypoints(lst)
+    for s in ss:
+        hip.sift_free_scalespace(s)
+
+
+def _list_from(hip, rows, p):
+    lst = hip.sift_malloc_keypoints()
+    for (x, y, sigma, theta, o, s) in rows:
+        key = hip.sift_malloc_keypoint(p.n_ori, p.n_hist, p.n_bins)
+        kc = key.contents
+        kc.x, kc.y, kc.sigma, kc.theta, kc.o, kc.s = x, y, sigma, theta, o, s
+        hip.sift_add_keypoint_to_list(key, lst)
+    return lst
+
+
+def test_only_description_and_orientation_variants(hip):
+    """Descriptors (and single orientations) for caller-supplied keypoints: feed the oracle's
+    own keypoints back in and expect its descriptors."""
+    img = synth.white(220, 160, 14)
+    p = abi.SiftParameters.default()
+    want = pyoracle.run(img, p, keep_ss=False)["keys"]
+    rows = [(f[0], f[1], f[2], f[3], i[0], i[1]) for f, i in zip(want["flts"], want["ints"])]
+    lst = _list_from(hip, rows, p)
+    hip.sift_anatomy_only_description(img.ctypes.data_as(abi.c_float_p), 220, 160, C.byref(p), lst)
+    got = abi.keypoints_to_numpy(lst)
+    assert np.array_equal(got["descr"], want["descr"])
+    hip.sift_free_keypoints(lst)
+
+    # one orientation per keypoint: compare with the reference library when it is available
+    if refrun.have_ref():
+        ref = refrun.ref_lib()
+        l_ref = _list_from(ref, rows, p)
+        l_hip = _list_from(hip, rows, p)
+        ref.sift_anatomy_orientation_and_description(img.ctypes.data_as(abi.c_float_p), 220, 160, C.byref(p), l_ref)
+        hip.sift_anatomy_orientation_and_description(img.ctypes.data_as(abi.c_float_p), 220, 160, C.byref(p), l_hip)
+        a, b = abi.keypoints_to_numpy(l_ref), abi.keypoints_to_numpy(l_hip)
+        assert same_bits(np.ascontiguousarray(a["flts"][:, 3]), np.ascontiguousarray(b["flts"][:, 3]))
+        assert np.array_equal(a["descr"], b["descr"]) and same_bits(a["orihist"], b["orihist"])
+        ref.sift_free_keypoints(l_ref)
+        hip.sift_free_keypoints(l_hip)
+
+
+def test_standalone_scalespace_and_gradient(hip):
+    img = synth.smooth(160, 120, 15)
+    want = pyoracle.run(img)
+    ss = hip.sift_malloc_scalespace_lowe(len(want["octaves"]), 3, 160, 120, C.c_float(0.5), C.c_float(0.8))
+    hip.scalespace_compute(ss, img.ctypes.data_as(abi.c_float_p), 160, 120, C.c_float(0.5))
+    g = abi.scalespace_to_numpy(ss)
+    for o in range(len(g)):
+        assert same_bits(g[o]["stack"], want["gss"][o])
+    sx = hip.sift_malloc_scalespace_from_model(ss)
+    sy = hip.sift_malloc_scalespace_from_model(ss)
+    hip.scalespace_compute_gradient(ss, sx, sy)
+    gx, gy = abi.scalespace_to_numpy(sx), abi.scalespace_to_numpy(sy)
+    for o in range(len(g)):
+        for s in range(g[o]["nSca"]):
+            gi, gj = pyoracle.gradient(want["gss"][o][s])
+            assert same_bits(gx[o]["stack"][s], gi) and same_bits(gy[o]["stack"][s], gj)
+    for s in (ss, sx, sy):
+        hip.sift_free_scalespace(s)
+
+
+def test_keypoint_text_format_round_trip(hip, tmp_path):
+    img = synth.white(200, 150, 16)
+    got = api.sift_compute_features(img)
+    path = str(tmp_path / "keys.txt").encode()
+    hip.sift_write_to_file.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    hip.sift_write_to_file(path, got.ctypes.data, len(got))
+    first = open(path).readline().split()
+    assert len(first) == 4 + 128 and first[0] == "%f" % got["x"][0]
+    hip.sift_read_from_file.restype = C.c_void_p
+    hip.sift_read_from_file.argtypes = [C.c_char_p, P(C.c_int)]
+    n = C.c_int()
+    back = _std_array(hip.sift_read_from_file(path, C.byref(n)), n.value)
+    assert n.value == len(got) and np.array_equal(back["descriptor"], got["descriptor"])
+    assert np.allclose(back["x"], got["x"], atol=1e-6, rtol=1e-6)

@@ -1,0 +1,57 @@
+"""GPU: the HIP library against the golden fixtures produced by the compiled reference,
+including the full-size 1080p and 4K inputs (bit-level digests of every scale-space octave,
+per-octave stage sizes, digests of the final keypoint table)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import sift_amd
+from sift_amd import abi, synth
+
+from test_oracle_golden import GOLD, INDEX, digest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_hip_reproduces_golden(hip, name):
+    e = INDEX[name]
+    img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
+    assert digest(img) == e["input_sha1"]
+    p = abi.SiftParameters.default().copy(**e["params"])
+    n_oct = e["n_oct"]
+    with sift_amd.Context(e["w"], e["h"], 1, p, keep_all_extrema=True) as ctx:
+        ctx.detect_host(img)
+        assert ctx.n_oct == n_oct and [list(d) for d in ctx.dims] == e["dims"]
+        sizes, ext = ctx.stage_counts(0)
+        assert ext.tolist() == e["stage_counts_per_octave"]["A"], "discrete extrema per octave"
+        seed, ref, stage = ctx.candidates(0)
+        for k, s in enumerate("ABCDEF"):
+            per_oct = np.bincount(seed["o"][stage >= k], minlength=n_oct)[:n_oct].tolist()
+            assert per_oct == e["stage_counts_per_octave"][s], f"stage {s} per octave"
+            assert sizes[k] == sum(per_oct)
+        for o in range(n_oct):
+            assert digest(ctx.scalespace(0, 0, o)) == e["gss_sha1"][o], f"gss octave {o} bits"
+            assert digest(ctx.scalespace(0, 1, o)) == e["dog_sha1"][o], f"dog octave {o} bits"
+        std, keys = ctx.keypoints(0)
+        orih, descr, src = ctx.extras(0)
+    assert len(std) == e["n_keys"]
+    ints = np.stack([keys["o"], keys["s"], keys["i"], keys["j"]], 1).astype(np.int32)
+    assert digest(ints) == e["keys_sha1"]["ints"]
+    path = os.path.join(GOLD, name + ".npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        xyst = np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1)
+        assert np.abs(xyst - g["flts"][:, :4]).max(initial=0) <= 1e-3           # stated tolerance
+        assert np.abs(std["descriptor"].astype(int) - g["descr"].astype(int)).max(initial=0) <= 1
+        assert np.array_equal(std["descriptor"], g["descr"])                     # and in fact exact
+        assert np.array_equal(xyst.view(np.uint32), g["flts"][:, :4].view(np.uint32))
+        assert np.array_equal(orih.view(np.uint32), g["orihist"].view(np.uint32))
+    else:
+        xyst = np.ascontiguousarray(np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1))
+        exact_xyst = digest(xyst) == e["keys_sha1"]["xyst"]
+        exact_descr = digest(np.ascontiguousarray(std["descriptor"])) == e["keys_sha1"]["descr_u8"]
+        print(name, "keys", len(std), "xyst exact", exact_xyst, "descr exact", exact_descr)
+        assert exact_xyst and exact_descr
