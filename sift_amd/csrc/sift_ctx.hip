@@ -220,8 +220,8 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     }
     if (L->n_sca < 4 || L->n_sca > SA_MAX_SCA) { sa_set_error("n_spo must be in 1..%d", SA_MAX_SCA - 3); return nullptr; }
     if (p->n_bins < 3 || p->n_bins > SA_MAX_BINS) { sa_set_error("n_bins must be in 3..%d", SA_MAX_BINS); return nullptr; }
-    if (p->n_hist < 1 || p->n_ori < 2 || p->n_hist * p->n_hist * p->n_ori > SA_MAX_DESCR) {
-        sa_set_error("descriptor shape n_hist=%d n_ori=%d unsupported (n_ori>=2, n_hist^2*n_ori<=%d)",
+    if (p->n_hist < 1 || p->n_hist > 8 || p->n_ori < 2 || p->n_hist * p->n_hist * p->n_ori > SA_MAX_DESCR) {
+        sa_set_error("descriptor shape n_hist=%d n_ori=%d unsupported (n_hist<=8, n_ori>=2, n_hist^2*n_ori<=%d)",
                      p->n_hist, p->n_ori, SA_MAX_DESCR);
         return nullptr;
     }

@@ -729,23 +729,37 @@ k_expand(const SaKey* __restrict__ keys, const int* __restrict__ index, int* __r
 
 // ------------------------------------------------------------- descriptor --
 // lib_description.c:278-347 (accumulation) and :374-389 (clip, renormalise, quantise),
-// driver loop lib_sift_anatomy.c:724-765.  One 256-thread block per keypoint.  The patch is
-// swept in raster order, 256 samples at a time: every thread evaluates one sample (rotation,
-// gradient, Gaussian weight, continuous bin coordinates) into LDS, then thread t < n_descr,
-// which owns descriptor bin t, walks the chunk in order and adds what falls into its bin.
-__global__ void __launch_bounds__(256)
+// driver loop lib_sift_anatomy.c:724-765.  One block of BS threads per keypoint.
+//
+// The reference adds every sample's (up to 2x2 cells) x (2 orientation bins) contributions
+// into float bins in raster order of the samples.  To get the same bits without serialising
+// everything, the patch is swept in raster order BS samples at a time:
+//   A. every thread evaluates one sample (rotation, gradient, Gaussian weight, the two
+//      double-precision contributions per touched cell);
+//   B. the contributions are appended to per-cell lists in LDS, in sample order (wave ballots
+//      give each sample its rank inside the wave, LDS counters the offsets between waves);
+//   C. thread t < n_descr, which owns descriptor bin t = (cell, k), walks its cell's list in
+//      order and adds the entries that fall into orientation bin k.
+// A bin receives at most one contribution per sample, so list order = reference order.
+#define SA_MAX_CELLS 64
+template <int BS>
+__global__ void __launch_bounds__(BS)
 k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
              int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
 {
-    __shared__ float e_a[256], e_b[256], e_g[256];
-    __shared__ double e_m[256];
+    constexpr int NW = BS / 64, POOL = 4 * BS;
+    __shared__ double p_cL[POOL], p_cR[POOL];
+    __shared__ int p_k[POOL];
+    __shared__ int wcount[NW][SA_MAX_CELLS];
+    __shared__ int cstart[SA_MAX_CELLS + 1];
     __shared__ float d_s[SA_MAX_DESCR];
     __shared__ float norm_s;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.y;
     const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
-    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb;
-    const int bi = tid / (Nh * Nb), bj = (tid / Nb) % Nh, bk = tid % Nb;
+    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
+    const int my_cell = tid / Nb, bk = tid % Nb;
+    const unsigned long long lt = lanemask_lt();
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         const SaKey key = keys[b * kcap + q];
         const SaOctave& oc = P.oct[key.o];
@@ -769,51 +783,96 @@ k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const in
         const float cell = __fdiv_rn(__fmul_rn(__fmul_rn(2.f, sc.lambda_descr), sk), (float)Nh);
         const double half = ((double)Nh - 1.0) / 2.0;
         float acc = 0.f;
-        for (int p0 = 0; p0 < npix; p0 += 256) {
+        for (int p0 = 0; p0 < npix; p0 += BS) {
+            // ---- A: one sample per thread
             const int p = p0 + tid;
-            float al = -100.f, be = -100.f, ga = 0.f;
-            double M = 0.0;
+            bool inside = false;
+            int a0 = 0, b0 = 0, k0 = 0;
+            double cL[4], cR[4];
             if (p < npix) {
                 const int si = i0 + p / nw, sj = j0 + p % nw;
                 const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
                 const float X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
                 const float Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
                 if (fmaxf(fabsf(X), fabsf(Y)) < R) {
+                    inside = true;
                     const double dx = (double)grad_i(im, w, h, si, sj);
                     const double dy = (double)grad_j(im, w, h, si, sj);
                     float ori = (float)(atan2(dy, dx) - (double)theta);
                     ori = modulus_f(ori, (float)(2 * SA_PI));
                     const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
-                    M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
-                    al = (float)((double)__fdiv_rn(X, cell) + half);
-                    be = (float)((double)__fdiv_rn(Y, cell) + half);
-                    ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                    const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
+                    const float al = (float)((double)__fdiv_rn(X, cell) + half);
+                    const float be = (float)((double)__fdiv_rn(Y, cell) + half);
+                    const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                    a0 = (int)floor((double)al);
+                    b0 = (int)floor((double)be);
+                    const double gf = floor((double)ga);
+                    k0 = ((int)ga + Nb) % Nb;
+                    const double wl = 1. - ((double)ga - gf);
+                    const double wr = 1.0 - (gf + 1 - (double)ga);
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const float da = fabsf(__fsub_rn((float)(a0 + (sl >> 1)), al));
+                        const float db = fabsf(__fsub_rn((float)(b0 + (sl & 1)), be));
+                        const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
+                        cL[sl] = wl * wa * wb * M;
+                        cR[sl] = wr * wa * wb * M;
+                    }
+                }
+            }
+            // ---- B: ordered append to the per-cell lists
+            int rank[4] = {0, 0, 0, 0};
+            for (int c = 0; c < ncell; ++c) {
+                const int di = c / Nh - a0, dj = c % Nh - b0;
+                const bool f = inside && (unsigned)di < 2u && (unsigned)dj < 2u;
+                const unsigned long long m = __ballot(f);
+                if (lane == 0) wcount[wave][c] = __popcll(m);
+                if (f) {
+                    const int r = __popcll(m & lt), sl = di * 2 + dj;
+                    if (sl == 0) rank[0] = r; else if (sl == 1) rank[1] = r;
+                    else if (sl == 2) rank[2] = r; else rank[3] = r;
                 }
             }
             __syncthreads();
-            e_a[tid] = al; e_b[tid] = be; e_g[tid] = ga; e_m[tid] = M;
+            if (wave == 0) {
+                int tot = 0;
+                if (lane < ncell)
+                    for (int v = 0; v < NW; ++v) tot += wcount[v][lane];
+                int inc = tot;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(inc, d);
+                    if (lane >= d) inc += t;
+                }
+                if (lane < ncell) cstart[lane] = inc - tot;
+                if (lane == ncell - 1) cstart[ncell] = inc;
+            }
             __syncthreads();
+            if (inside) {
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
+                    if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
+                        const int c = ci * Nh + cj;
+                        int pos = cstart[c] + rank[sl];
+                        for (int v = 0; v < wave; ++v) pos += wcount[v][c];
+                        p_k[pos] = k0; p_cL[pos] = cL[sl]; p_cR[pos] = cR[sl];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- C: bin owners consume their cell's list in order
             if (tid < nd) {
-                const int lim = min(256, npix - p0);
-                for (int e = 0; e < lim; ++e) {
-                    const float a = e_a[e];
-                    const float da = fabsf(__fsub_rn((float)bi, a));
-                    if (!(da < 1.f)) continue;
-                    const float db = fabsf(__fsub_rn((float)bj, e_b[e]));
-                    if (!(db < 1.f)) continue;
-                    const float g = e_g[e];
-                    const int gi = (int)g;
-                    const double gf = floor((double)g);
-                    const int k0 = (gi + Nb) % Nb, k1 = (gi + 1 + Nb) % Nb;
-                    const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
-                    if (bk == k0)
-                        acc = (float)((double)acc + (1. - ((double)g - gf)) * wa * wb * e_m[e]);
-                    if (bk == k1)
-                        acc = (float)((double)acc + (1.0 - (gf + 1 - (double)g)) * wa * wb * e_m[e]);
+                const int e1 = cstart[my_cell + 1];
+                const int k1 = bk == 0 ? Nb - 1 : bk - 1;      // bin whose right neighbour is bk
+                for (int e = cstart[my_cell]; e < e1; ++e) {
+                    const int kk = p_k[e];
+                    if (kk == bk) acc = (float)((double)acc + p_cL[e]);
+                    else if (kk == k1) acc = (float)((double)acc + p_cR[e]);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         if (tid < nd) d_s[tid] = acc;
         __syncthreads();
         // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
@@ -979,8 +1038,12 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
                        const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
                        int batch)
 {
-    HIPK(k_descriptor, dim3(1024, batch), dim3(256), 0, st, P, sc, keys, counters, cnt_slot, kcap,
-         out_std, out_descr);
+    if (sc.n_hist * sc.n_hist * sc.n_ori <= 128)
+        HIPK(k_descriptor<128>, dim3(2048, batch), dim3(128), 0, st, P, sc, keys, counters, cnt_slot, kcap,
+             out_std, out_descr);
+    else
+        HIPK(k_descriptor<256>, dim3(1024, batch), dim3(256), 0, st, P, sc, keys, counters, cnt_slot, kcap,
+             out_std, out_descr);
 }
 
 }  // namespace sa
