@@ -124,8 +124,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable([api.K_BLUR_H])
-    ctx.profile_read(api.K_BLUR_H, -1, reset=True)
+    fused = os.environ.get("SIFT_AMD_BLUR", "fused") != "split"
+    dom = api.K_BLUR_FUSED if fused else api.K_BLUR_H
+    ctx.profile_enable([dom])
+    ctx.profile_read(dom, -1, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -143,14 +145,21 @@ def main():
 
     if rank == 0:
         total_images = B * world * args.steps
-        # dominant kernel: the row pass of the blur with the DoG epilogue, octave 0.
-        # Algorithmic bytes per launch: it reads the column-pass result (4 B/px) and the previous
-        # Gaussian image (4 B/px, for the DoG) and writes the new Gaussian image and the DoG image
-        # (4 B/px each) -> 16 B/px; the seed launch has no DoG -> 8 B/px.
+        # Dominant kernel: the Gaussian blur of octave 0 (6 launches per step: seed + 5 scales).
+        # Algorithmic bytes per pixel and launch, fused kernel: read the source image (4 B), write
+        # the blurred image (4 B) and the DoG image (4 B) = 12 B; the seed launch writes no DoG
+        # (8 B); the launch that also emits the next octave's first image adds 1 B (a quarter of
+        # the pixels).  Two-kernel form, row pass: read column-pass image and previous Gaussian
+        # image, write Gaussian and DoG image = 16 B (seed 8 B).
         n0 = ctx.dims[0][0] * ctx.dims[0][1]
-        ms, launches = ctx.profile_read(api.K_BLUR_H, 0)
-        per_step = ctx.n_sca                       # seed + (n_sca-1) steps in octave 0
-        bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))
+        ms, launches = ctx.profile_read(dom, 0)
+        per_step = ctx.n_sca                       # seed + (n_sca-1) scales in octave 0
+        if fused:
+            bytes_per_step = B * n0 * (8 + 12 * (ctx.n_sca - 1) + (1 if ctx.n_oct > 1 else 0))
+            kname = "k_blur_fused (column+row pass, DoG epilogue), octave 0"
+        else:
+            bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))
+            kname = "k_blur_h (row pass + DoG epilogue), octave 0"
         steps_timed = launches / per_step if per_step else 0
         achieved = (bytes_per_step * steps_timed) / (ms * 1e-3) / 1e9 if ms > 0 else None
         traffic = load_traffic()
@@ -180,7 +189,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_blur_h (row pass + DoG epilogue), octave 0",
+                "kernel": kname,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

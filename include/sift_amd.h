@@ -164,7 +164,7 @@ enum {
 enum {
     SIFT_AMD_K_OVERSAMPLE = 0, SIFT_AMD_K_SUBSAMPLE, SIFT_AMD_K_BLUR_V, SIFT_AMD_K_BLUR_H,
     SIFT_AMD_K_EXTREMA, SIFT_AMD_K_REFINE, SIFT_AMD_K_RANK, SIFT_AMD_K_ORIENTATION,
-    SIFT_AMD_K_EXPAND, SIFT_AMD_K_DESCRIPTOR, SIFT_AMD_K_COUNT
+    SIFT_AMD_K_EXPAND, SIFT_AMD_K_DESCRIPTOR, SIFT_AMD_K_BLUR_FUSED, SIFT_AMD_K_COUNT
 };
 
 struct sift_amd_geometry {

@@ -18,9 +18,9 @@ LIB_PATH = os.path.join(HERE, "libsift_amd.so")
 
 MAX_OCT, MAX_SCA = 16, 12
 K_OVERSAMPLE, K_SUBSAMPLE, K_BLUR_V, K_BLUR_H, K_EXTREMA, K_REFINE, K_RANK, K_ORIENTATION, \
-    K_EXPAND, K_DESCRIPTOR, K_COUNT = range(11)
+    K_EXPAND, K_DESCRIPTOR, K_BLUR_FUSED, K_COUNT = range(12)
 KERNEL_CLASSES = ["oversample", "subsample", "blur_v", "blur_h", "extrema", "refine", "rank",
-                  "orientation", "expand", "descriptor"]
+                  "orientation", "expand", "descriptor", "blur_fused"]
 KEEP_ALL_EXTREMA = 1
 
 

@@ -134,6 +134,7 @@ struct sift_amd_ctx {
     SaScalars sc;
     BlurSpec seed;
     BlurSpec step[SA_MAX_OCT][SA_MAX_SCA];
+    bool fused_blur = true;         // SIFT_AMD_BLUR=split selects the two-kernel form
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     int last_n = 0;
@@ -233,6 +234,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     c->device = device; c->im_w = im_w; c->im_h = im_h; c->batch = max_batch; c->flags = flags;
     c->p = *p; c->L = *L; c->sigma_in = sigma_in;
     auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
+    if (const char* m = getenv("SIFT_AMD_BLUR")) c->fused_blur = strcmp(m, "split") != 0;
 
     for (int o = 1; o < L->n_oct; o++)
         if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
@@ -416,28 +418,25 @@ extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, doubl
 // ---------------------------------------------------------------- pipeline --
 
 static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
-                     float* out, long long s_out, float* dog, long long s_dog, int n)
+                     float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n)
 {
     sa::BlurArgs a;
-    a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog;
-    a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog;
+    a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog; a.sub = sub;
+    a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog; a.s_sub = s_sub;
     a.w = c->L.w[o]; a.h = c->L.h[o]; a.batch = n;
     a.radius = b.radius; a.taps = b.taps; a.taps_dev = b.taps_dev;
-    sa::launch_blur_profiled(st, a, c, o);
-}
-
-namespace sa {
-void launch_blur_profiled(hipStream_t st, const BlurArgs& a, sift_amd_ctx* c, int o)
-{
-    if (c->prof_mask & ((1u << SIFT_AMD_K_BLUR_V) | (1u << SIFT_AMD_K_BLUR_H))) {
-        { ProfScope ps(c, st, SIFT_AMD_K_BLUR_V, o); launch_blur_pass(st, a, 0); }
-        { ProfScope ps(c, st, SIFT_AMD_K_BLUR_H, o); launch_blur_pass(st, a, 1); }
-    } else {
-        launch_blur_pass(st, a, 0);
-        launch_blur_pass(st, a, 1);
+    if (c->fused_blur && b.radius >= 1 && b.radius <= SA_MAX_RADIUS_FAST) {
+        ProfScope ps(c, st, SIFT_AMD_K_BLUR_FUSED, o);
+        sa::launch_blur_fused(st, a);
+        return;
+    }
+    { ProfScope ps(c, st, SIFT_AMD_K_BLUR_V, o); sa::launch_blur_pass(st, a, 0); }
+    { ProfScope ps(c, st, SIFT_AMD_K_BLUR_H, o); sa::launch_blur_pass(st, a, 1); }
+    if (sub) {
+        ProfScope ps(c, st, SIFT_AMD_K_SUBSAMPLE, o + 1);
+        sa::launch_subsample(st, out, a.w, s_out, sub, a.w / 2, a.h / 2, s_sub, n);
     }
 }
-}  // namespace sa
 
 int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st)
 {
@@ -453,18 +452,22 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 { ProfScope ps(c, st, SIFT_AMD_K_OVERSAMPLE, 0);
                   sa::launch_oversample(st, d_images, c->im_w, c->im_h, (long long)c->im_w * c->im_h,
                                         c->d_seed, L.w[0], L.h[0], np, L.delta[0], n); }
-                run_blur(c, st, 0, c->seed, c->d_seed, np, g, sg, nullptr, 0, n);
+                run_blur(c, st, 0, c->seed, c->d_seed, np, g, sg, nullptr, 0, nullptr, 0, n);
             } else {
-                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, n);
+                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n);
             }
-        } else {
-            const long long npp = (long long)L.w[o - 1] * L.h[o - 1];
-            ProfScope ps(c, st, SIFT_AMD_K_SUBSAMPLE, o);
-            sa::launch_subsample(st, c->d_gss[o - 1] + (ns - 3) * npp, L.w[o - 1], ns * npp,
-                                 g, L.w[o], L.h[o], sg, n);
         }
-        for (int s = 1; s < ns; s++)
-            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, n);
+        // octaves o > 0 start from the even samples of image n_spo of the octave below
+        // (lib_sift_anatomy.c:142-149), written by that image's blur
+        for (int s = 1; s < ns; s++) {
+            float* sub = nullptr;
+            long long s_sub = 0;
+            if (s == ns - 3 && o + 1 < L.n_oct) {
+                sub = c->d_gss[o + 1];
+                s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
+            }
+            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, sub, s_sub, n);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("scale-space launch failed: %s", hipGetErrorString(e)); return -1; }

@@ -214,6 +214,125 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
     }
 }
 
+// Both passes in one kernel.  A block owns 224 output columns (256 with the 16-column halo on
+// each side) and walks down a strip of rows, 8 rows per iteration:
+//   - column pass as in k_blur_v: thread t keeps the 2R+8 newest samples of extended column t
+//     in registers and produces 8 column-filtered samples, which go to LDS together with the
+//     8 unfiltered centre samples (needed for the DoG);
+//   - row pass: thread (row g, group q) reads 40 consecutive column-filtered samples of row g
+//     from LDS and produces 8 adjacent outputs, stored with 16-byte accesses.
+// Per pixel the kernel reads the source image once (plus the strip/tile halo, served by L2)
+// and writes gss[s] and dog[s-1]; the column-pass image never exists in memory.  Operation
+// order per output is identical to the two-kernel form, so results are bit-identical.
+// `sub`, if given, receives the even samples (the next octave's first image,
+// lib_discrete.c:180-191).
+template <int R>
+__global__ void __launch_bounds__(256)
+k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
+             float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
+             long long s_dog, long long s_sub, SaTaps tp, int strip)
+{
+    constexpr int G = 8, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 8;
+    __shared__ __attribute__((aligned(16))) float l_tmp[2][G][EW];
+    __shared__ __attribute__((aligned(16))) float l_prev[2][G][EW];
+    const int tid = threadIdx.x;
+    const long long b = blockIdx.z;
+    const int x0 = blockIdx.x * TW;
+    const float* src = in + b * s_in + mirror_idx(x0 - RP + tid, w);
+    const int i0 = blockIdx.y * strip;
+    const int i1 = min(i0 + strip, h);
+    const int hg = tid / NG, hq = tid - hg * NG;
+    const int xo = x0 + 8 * hq;
+    const bool hact = tid < G * NG && xo < w;
+    const bool vec = ((w & 3) == 0) && (xo + 8 <= w);
+    const int wo = w >> 1, ho = h >> 1;
+
+    float win[G + 2 * R];
+    float nx[G];
+#pragma unroll
+    for (int t = 0; t < 2 * R; ++t) win[t] = src[(long long)mirror_idx(i0 - R + t, h) * w];
+#pragma unroll
+    for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(i0 + R + g, h) * w];
+
+    int buf = 0;
+    for (int ii = i0; ii < i1; ii += G, buf ^= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
+        if (ii + G < i1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(ii + G + R + g, h) * w];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float s = __fmul_rn(win[g + R], tp.g[0]);
+#pragma unroll
+            for (int k = 1; k <= R; ++k)
+                s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[g + R - k], win[g + R + k])));
+            l_tmp[buf][g][tid] = s;
+            l_prev[buf][g][tid] = win[g + R];
+        }
+        __syncthreads();
+        const int row = ii + hg;
+        if (hact && row < i1) {
+            float hw[8 + 2 * RP];
+            const float* lrow = &l_tmp[buf][hg][8 * hq];
+#pragma unroll
+            for (int q = 0; q < (8 + 2 * RP) / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(lrow + 4 * q);
+                hw[4 * q + 0] = v.x; hw[4 * q + 1] = v.y; hw[4 * q + 2] = v.z; hw[4 * q + 3] = v.w;
+            }
+            float o8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float s = __fmul_rn(hw[RP + q], tp.g[0]);
+#pragma unroll
+                for (int k = 1; k <= R; ++k)
+                    s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
+                o8[q] = s;
+            }
+            const long long off = (long long)row * w + xo;
+            float* po = out + b * s_out + off;
+            if (vec) {
+                *reinterpret_cast<float4*>(po) = make_float4(o8[0], o8[1], o8[2], o8[3]);
+                *reinterpret_cast<float4*>(po + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (xo + q < w) po[q] = o8[q];
+            }
+            if (dog) {
+                const float* lp = &l_prev[buf][hg][RP + 8 * hq];
+                const float4 p0 = *reinterpret_cast<const float4*>(lp);
+                const float4 p1 = *reinterpret_cast<const float4*>(lp + 4);
+                float* pd = dog + b * s_dog + off;
+                const float d8[8] = {__fsub_rn(o8[0], p0.x), __fsub_rn(o8[1], p0.y), __fsub_rn(o8[2], p0.z),
+                                     __fsub_rn(o8[3], p0.w), __fsub_rn(o8[4], p1.x), __fsub_rn(o8[5], p1.y),
+                                     __fsub_rn(o8[6], p1.z), __fsub_rn(o8[7], p1.w)};
+                if (vec) {
+                    *reinterpret_cast<float4*>(pd) = make_float4(d8[0], d8[1], d8[2], d8[3]);
+                    *reinterpret_cast<float4*>(pd + 4) = make_float4(d8[4], d8[5], d8[6], d8[7]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (xo + q < w) pd[q] = d8[q];
+                }
+            }
+            if (sub && !(row & 1) && (row >> 1) < ho) {
+                float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
+                if (((wo & 3) == 0) && (xo >> 1) + 4 <= wo) {
+                    *reinterpret_cast<float4*>(ps) = make_float4(o8[0], o8[2], o8[4], o8[6]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if ((xo >> 1) + q < wo) ps[q] = o8[2 * q];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2 * R; ++t) win[t] = win[t + G];
+    }
+}
+
 // Any radius (taps in global memory); one thread per output sample.  Only used for
 // radii above SA_MAX_RADIUS_FAST, i.e. non-default parameters.
 __global__ void __launch_bounds__(256)
@@ -930,6 +1049,28 @@ static void blur_h_t(hipStream_t st, const BlurArgs& a)
     case 5: F(5); break; case 6: F(6); break; case 7: F(7); break; case 8: F(8); break; \
     case 9: F(9); break; case 10: F(10); break; case 11: F(11); break; case 12: F(12); break; \
     case 13: F(13); break; case 14: F(14); break; case 15: F(15); break; case 16: F(16); break;
+
+template <int R>
+static void blur_fused_t(hipStream_t st, const BlurArgs& a)
+{
+    const int strip = 128;
+    dim3 grid((a.w + 223) / 224, (a.h + strip - 1) / strip, a.batch);
+    HIPK(k_blur_fused<R>, grid, dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+         a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip);
+}
+
+// Single-kernel blur (column + row pass, DoG and optional subsample epilogue).
+// Returns false if the radius has no register-window instantiation.
+bool launch_blur_fused(hipStream_t st, const BlurArgs& a)
+{
+    if (a.radius < 1 || a.radius > SA_MAX_RADIUS_FAST) return false;
+    switch (a.radius) {
+#define F(R) blur_fused_t<R>(st, a)
+        SA_R_CASES(F)
+#undef F
+    }
+    return true;
+}
 
 // pass 0: column pass (in -> tmp); pass 1: row pass (tmp -> out [, dog = out - in]).
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass)

@@ -13,7 +13,8 @@ struct BlurArgs {
     float* tmp;          // column-pass result       [batch] stride s_tmp
     float* out;          // blurred images           [batch] stride s_out
     float* dog;          // optional: out - in       [batch] stride s_dog (nullptr = skip)
-    long long s_in, s_tmp, s_out, s_dog;
+    float* sub;          // optional: even samples of out (next octave), fused kernel only
+    long long s_in, s_tmp, s_out, s_dog, s_sub;
     int w, h, batch;
     int radius;
     SaTaps taps;             // radius <= SA_MAX_RADIUS_FAST
@@ -21,7 +22,7 @@ struct BlurArgs {
 };
 
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
-void launch_blur_profiled(hipStream_t st, const BlurArgs& a, struct ::sift_amd_ctx* c, int octave);
+bool launch_blur_fused(hipStream_t st, const BlurArgs& a);
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
                        float* out, int wo, int ho, long long s_out, float delta, int batch);
 void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,
