@@ -137,3 +137,35 @@ def test_keypoint_text_format_round_trip(hip, tmp_path):
     back = _std_array(hip.sift_read_from_file(path, C.byref(n)), n.value)
     assert n.value == len(got) and np.array_equal(back["descriptor"], got["descriptor"])
     assert np.allclose(back["x"], got["x"], atol=1e-6, rtol=1e-6)
+
+
+def test_c_host_program_links_and_runs(hip, tmp_path):
+    """Compiles a C host (tests/c_host/host_example.c) against include/sift_amd.h and the shared
+    library with gcc and runs it: the drop-in boundary exercised from C, not from ctypes."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    img = synth.white(256, 192, 17)
+    raw = str(tmp_path / "img.f32")
+    img.tofile(raw)
+    exe = str(tmp_path / "host_example")
+    libdir = os.path.join(root, "sift_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", os.path.join(root, "tests", "c_host", "host_example.c"),
+                           "-I", os.path.join(root, "include"), "-L", libdir, "-lsift_amd",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    out = str(tmp_path / "keys.txt")
+    res = subprocess.run([exe, raw, "256", "192", out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    want = pyoracle.run(img)
+    nums = [int(v) for v in res.stdout.split()]
+    assert nums[0] == nums[1] == len(want["keys"]["ints"])
+    assert nums[2:8] == [len(want["stages"][s]["ints"]) for s in "ABCDEF"]
+    assert nums[8] == len(want["octaves"]) and nums[9] == 5
+    lines = open(out).read().splitlines()
+    assert len(lines) == len(want["keys"]["ints"])
+    first = lines[0].split()
+    assert first[:4] == ["%f" % v for v in want["keys"]["flts"][0, :4]]
+    assert [int(v) for v in first[4:]] == want["keys"]["descr"][0].astype(int).tolist()
