@@ -11,7 +11,7 @@ SOURCES = ["sift_kernels.hip", "sift_ctx.hip", "sift_compat.hip"]
 # -ffp-contract=off is part of the numerical contract: the blur/DoG/refinement arithmetic must
 # not be fused into FMAs (see the header of sift_kernels.hip).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SIFT_AMD_EXTRA_FLAGS", "").split()
 
 
 def _stale():

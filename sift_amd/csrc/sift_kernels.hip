@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "sift_dev.h"
 #include "sift_launch.h"
@@ -30,6 +32,16 @@ __device__ __forceinline__ int mirror_idx(int i, int l)
     if (i < 0) i += ll;
     if (i > l - 1) i = ll - 1 - i;
     return i;
+}
+
+// Blocks are dealt round-robin to the 8 XCDs (each with its own L2) in launch order.  For
+// kernels whose neighbouring tiles share halo data, remap the linear block id so that every
+// XCD works on one contiguous range of tiles: blocks l and l+8 (same XCD) become neighbours.
+// Bijective for any block count; affects speed only.
+__device__ __forceinline__ unsigned xcd_remap(unsigned l, unsigned total)
+{
+    const unsigned q = total >> 3, r = total & 7u, x = l & 7u;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (l >> 3);
 }
 
 // lane i receives the value of lane i-1 / i+1 of the wave (edge lanes receive 0).
@@ -219,8 +231,9 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
 //   - column pass as in k_blur_v: thread t keeps the 2R+8 newest samples of extended column t
 //     in registers and produces 8 column-filtered samples, which go to LDS together with the
 //     8 unfiltered centre samples (needed for the DoG);
-//   - row pass: thread (row g, group q) reads 40 consecutive column-filtered samples of row g
-//     from LDS and produces 8 adjacent outputs, stored with 16-byte accesses.
+//   - row pass: thread (row g, group q) reads 36 consecutive column-filtered samples of row g
+//     from LDS and produces 4 adjacent outputs, stored with 16-byte accesses (448 such items
+//     per iteration, two per thread).
 // Per pixel the kernel reads the source image once (plus the strip/tile halo, served by L2)
 // and writes gss[s] and dog[s-1]; the column-pass image never exists in memory.  Operation
 // order per output is identical to the two-kernel form, so results are bit-identical.
@@ -230,21 +243,26 @@ template <int R>
 __global__ void __launch_bounds__(256)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
-             long long s_dog, long long s_sub, SaTaps tp, int strip)
+             long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks)
 {
-    constexpr int G = 8, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 8;
-    __shared__ __attribute__((aligned(16))) float l_tmp[2][G][EW];
-    __shared__ __attribute__((aligned(16))) float l_prev[2][G][EW];
+    // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
+    // the row pass free of bank conflicts also where a wave straddles two rows.
+    constexpr int G = 8, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
+    constexpr int ITEMS = G * NG;
+#ifndef SA_BLUR_NBUF
+#define SA_BLUR_NBUF 2
+#endif
+    __shared__ __attribute__((aligned(16))) float l_tmp[SA_BLUR_NBUF][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float l_prev[SA_BLUR_NBUF][G][PITCH];
     const int tid = threadIdx.x;
-    const long long b = blockIdx.z;
-    const int x0 = blockIdx.x * TW;
+    const unsigned vid = xcd_remap(blockIdx.x, nblocks);
+    const int bx = vid % nbx, by = (vid / nbx) % nby;
+    const long long b = vid / (nbx * nby);
+    const int x0 = bx * TW;
     const float* src = in + b * s_in + mirror_idx(x0 - RP + tid, w);
-    const int i0 = blockIdx.y * strip;
+    const int i0 = by * strip;
     const int i1 = min(i0 + strip, h);
-    const int hg = tid / NG, hq = tid - hg * NG;
-    const int xo = x0 + 8 * hq;
-    const bool hact = tid < G * NG && xo < w;
-    const bool vec = ((w & 3) == 0) && (xo + 8 <= w);
+    const bool vec_w = (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
 
     float win[G + 2 * R];
@@ -255,13 +273,14 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(i0 + R + g, h) * w];
 
     int buf = 0;
-    for (int ii = i0; ii < i1; ii += G, buf ^= 1) {
+    for (int ii = i0; ii < i1; ii += G, buf ^= (SA_BLUR_NBUF - 1)) {
 #pragma unroll
         for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
         if (ii + G < i1) {
 #pragma unroll
             for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(ii + G + R + g, h) * w];
         }
+        if (SA_BLUR_NBUF == 1) __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float s = __fmul_rn(win[g + R], tp.g[0]);
@@ -272,59 +291,55 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             l_prev[buf][g][tid] = win[g + R];
         }
         __syncthreads();
-        const int row = ii + hg;
-        if (hact && row < i1) {
-            float hw[8 + 2 * RP];
-            const float* lrow = &l_tmp[buf][hg][8 * hq];
 #pragma unroll
-            for (int q = 0; q < (8 + 2 * RP) / 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(lrow + 4 * q);
-                hw[4 * q + 0] = v.x; hw[4 * q + 1] = v.y; hw[4 * q + 2] = v.z; hw[4 * q + 3] = v.w;
-            }
-            float o8[8];
+        for (int rnd = 0; rnd < (ITEMS + 255) / 256; ++rnd) {
+            const int item = rnd * 256 + tid;
+            const int hg = item / NG, hq = item - hg * NG;
+            const int row = ii + hg, xo = x0 + 4 * hq;
+            if (item < ITEMS && row < i1 && xo < w) {
+                float hw[4 + 2 * RP];
+                const float* lrow = &l_tmp[buf][hg][4 * hq];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float s = __fmul_rn(hw[RP + q], tp.g[0]);
-#pragma unroll
-                for (int k = 1; k <= R; ++k)
-                    s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
-                o8[q] = s;
-            }
-            const long long off = (long long)row * w + xo;
-            float* po = out + b * s_out + off;
-            if (vec) {
-                *reinterpret_cast<float4*>(po) = make_float4(o8[0], o8[1], o8[2], o8[3]);
-                *reinterpret_cast<float4*>(po + 4) = make_float4(o8[4], o8[5], o8[6], o8[7]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (xo + q < w) po[q] = o8[q];
-            }
-            if (dog) {
-                const float* lp = &l_prev[buf][hg][RP + 8 * hq];
-                const float4 p0 = *reinterpret_cast<const float4*>(lp);
-                const float4 p1 = *reinterpret_cast<const float4*>(lp + 4);
-                float* pd = dog + b * s_dog + off;
-                const float d8[8] = {__fsub_rn(o8[0], p0.x), __fsub_rn(o8[1], p0.y), __fsub_rn(o8[2], p0.z),
-                                     __fsub_rn(o8[3], p0.w), __fsub_rn(o8[4], p1.x), __fsub_rn(o8[5], p1.y),
-                                     __fsub_rn(o8[6], p1.z), __fsub_rn(o8[7], p1.w)};
-                if (vec) {
-                    *reinterpret_cast<float4*>(pd) = make_float4(d8[0], d8[1], d8[2], d8[3]);
-                    *reinterpret_cast<float4*>(pd + 4) = make_float4(d8[4], d8[5], d8[6], d8[7]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (xo + q < w) pd[q] = d8[q];
+                for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(lrow + 4 * q);
+                    hw[4 * q + 0] = v.x; hw[4 * q + 1] = v.y; hw[4 * q + 2] = v.z; hw[4 * q + 3] = v.w;
                 }
-            }
-            if (sub && !(row & 1) && (row >> 1) < ho) {
-                float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
-                if (((wo & 3) == 0) && (xo >> 1) + 4 <= wo) {
-                    *reinterpret_cast<float4*>(ps) = make_float4(o8[0], o8[2], o8[4], o8[6]);
+                float o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float s = __fmul_rn(hw[RP + q], tp.g[0]);
+#pragma unroll
+                    for (int k = 1; k <= R; ++k)
+                        s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
+                    o4[q] = s;
+                }
+                const bool vec = vec_w && (xo + 4 <= w);
+                const long long off = (long long)row * w + xo;
+                float* po = out + b * s_out + off;
+                if (vec) {
+                    *reinterpret_cast<float4*>(po) = make_float4(o4[0], o4[1], o4[2], o4[3]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if ((xo >> 1) + q < wo) ps[q] = o8[2 * q];
+                        if (xo + q < w) po[q] = o4[q];
+                }
+                if (dog) {
+                    const float4 pv = *reinterpret_cast<const float4*>(&l_prev[buf][hg][RP + 4 * hq]);
+                    float* pd = dog + b * s_dog + off;
+                    const float d4[4] = {__fsub_rn(o4[0], pv.x), __fsub_rn(o4[1], pv.y),
+                                         __fsub_rn(o4[2], pv.z), __fsub_rn(o4[3], pv.w)};
+                    if (vec) {
+                        *reinterpret_cast<float4*>(pd) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (xo + q < w) pd[q] = d4[q];
+                    }
+                }
+                if (sub && !(row & 1) && (row >> 1) < ho) {
+                    float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
+                    if ((xo >> 1) < wo) ps[0] = o4[0];
+                    if ((xo >> 1) + 1 < wo) ps[1] = o4[2];
                 }
             }
         }
@@ -1023,6 +1038,216 @@ k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const in
     }
 }
 
+// Wave-per-keypoint form of the descriptor kernel (the default).  Same arithmetic and the same
+// per-bin order of additions as k_descriptor above, but one 64-lane wave owns a keypoint, so no
+// block-wide barriers are needed, and the samples that fall inside the rotated window are first
+// queued (in raster order) so that the expensive double-precision part always runs on full
+// waves.  Lane l owns the BPL consecutive descriptor bins l*BPL .. l*BPL+BPL-1.
+template <int BPL>
+__global__ void __launch_bounds__(64)
+k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
+                  int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
+{
+    constexpr int POOL = 256;
+    __shared__ double p_cL[POOL], p_cR[POOL];
+    __shared__ int p_k[POOL];
+    __shared__ int q_pix[128];
+    __shared__ int cstart[SA_MAX_CELLS + 1];
+    __shared__ float d_s[SA_MAX_DESCR];
+    __shared__ float norm_s;
+    const int lane = threadIdx.x;
+    const long long b = blockIdx.y;
+    const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
+    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
+    const unsigned long long lt = lanemask_lt();
+    int my_cell[BPL], my_k[BPL], my_kprev[BPL];
+#pragma unroll
+    for (int u = 0; u < BPL; ++u) {
+        const int t = lane * BPL + u;
+        my_cell[u] = t < nd ? t / Nb : -1;
+        my_k[u] = t % Nb;
+        my_kprev[u] = my_k[u] == 0 ? Nb - 1 : my_k[u] - 1;
+    }
+    for (int q = blockIdx.x; q < n; q += gridDim.x) {
+        const SaKey key = keys[b * kcap + q];
+        const SaOctave& oc = P.oct[key.o];
+        const int w = oc.w, h = oc.h;
+        const float* im = oc.gss + b * oc.gss_stride + (long long)key.s * w * h;
+        const float xk = __fdiv_rn(key.x, oc.delta), yk = __fdiv_rn(key.y, oc.delta);
+        const float sk = __fdiv_rn(key.sigma, oc.delta);
+        const float theta = key.theta;
+        const float R = __fmul_rn(__fmul_rn(__fadd_rn(1.f, __fdiv_rn(1.f, (float)Nh)), sc.lambda_descr), sk);
+        const float Rp = (float)(SA_SQRT2 * (double)R);
+        const int i0 = max(0, (int)((double)__fsub_rn(xk, Rp) + 0.5));
+        const int j0 = max(0, (int)((double)__fsub_rn(yk, Rp) + 0.5));
+        const int i1 = min((int)((double)__fadd_rn(xk, Rp) + 0.5), h - 1);
+        const int j1 = min((int)((double)__fadd_rn(yk, Rp) + 0.5), w - 1);
+        const int nw = j1 - j0, nh = i1 - i0;                 // upper bounds are exclusive
+        const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
+        const float ma = -theta;
+        const float ct = (float)cos((double)ma), st = (float)sin((double)ma);
+        const double tt = (double)__fmul_rn(sc.lambda_descr, sk);
+        const double two_t2 = 2 * tt * tt;
+        const float cell = __fdiv_rn(__fmul_rn(__fmul_rn(2.f, sc.lambda_descr), sk), (float)Nh);
+        const double half = ((double)Nh - 1.0) / 2.0;
+        float acc[BPL];
+#pragma unroll
+        for (int u = 0; u < BPL; ++u) acc[u] = 0.f;
+
+        int qn = 0, p0 = 0;
+        while (p0 < npix || qn > 0) {
+            // ---- queue the samples inside the rotated window, in raster order
+            while (qn < 64 && p0 < npix) {
+                const int p = p0 + lane;
+                bool in_win = false;
+                if (p < npix) {
+                    const int si = i0 + p / nw, sj = j0 + p % nw;
+                    const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
+                    const float X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
+                    const float Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
+                    in_win = fmaxf(fabsf(X), fabsf(Y)) < R;
+                }
+                const unsigned long long m = __ballot(in_win);
+                if (in_win) q_pix[qn + __popcll(m & lt)] = p;
+                qn += __popcll(m);
+                p0 += 64;
+            }
+            __syncthreads();
+            const int nproc = min(qn, 64);
+            const bool act = lane < nproc;
+            // ---- geometry of my sample, cell ranks
+            int si = 0, sj = 0, a0 = 0, b0 = 0;
+            float X = 0.f, Y = 0.f, al = 0.f, be = 0.f;
+            if (act) {
+                const int p = q_pix[lane];
+                si = i0 + p / nw; sj = j0 + p % nw;
+                const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
+                X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
+                Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
+                al = (float)((double)__fdiv_rn(X, cell) + half);
+                be = (float)((double)__fdiv_rn(Y, cell) + half);
+                a0 = (int)floor((double)al);
+                b0 = (int)floor((double)be);
+            }
+            int rank[4] = {0, 0, 0, 0};
+            int cnt_mine = 0;                       // lane c < ncell keeps the size of list c
+            for (int c = 0; c < ncell; ++c) {
+                const int di = c / Nh - a0, dj = c % Nh - b0;
+                const bool f = act && (unsigned)di < 2u && (unsigned)dj < 2u;
+                const unsigned long long m = __ballot(f);
+                if (lane == c) cnt_mine = __popcll(m);
+                if (f) {
+                    const int r = __popcll(m & lt), sl = di * 2 + dj;
+                    if (sl == 0) rank[0] = r; else if (sl == 1) rank[1] = r;
+                    else if (sl == 2) rank[2] = r; else rank[3] = r;
+                }
+            }
+            {
+                int inc = cnt_mine;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(inc, d);
+                    if (lane >= d) inc += t;
+                }
+                if (lane < ncell) cstart[lane] = inc - cnt_mine;
+                if (lane == ncell - 1) cstart[ncell] = inc;
+            }
+            __syncthreads();
+            // ---- contributions of my sample, appended to the lists of the cells it touches
+            if (act) {
+                const double dx = (double)grad_i(im, w, h, si, sj);
+                const double dy = (double)grad_j(im, w, h, si, sj);
+                float ori = (float)(atan2(dy, dx) - (double)theta);
+                ori = modulus_f(ori, (float)(2 * SA_PI));
+                const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
+                const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
+                const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                const double gf = floor((double)ga);
+                const int k0 = ((int)ga + Nb) % Nb;
+                const double wl = 1. - ((double)ga - gf);
+                const double wr = 1.0 - (gf + 1 - (double)ga);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
+                    if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
+                        const float da = fabsf(__fsub_rn((float)ci, al));
+                        const float db = fabsf(__fsub_rn((float)cj, be));
+                        const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
+                        const int pos = cstart[ci * Nh + cj] + rank[sl];
+                        p_k[pos] = k0;
+                        p_cL[pos] = wl * wa * wb * M;
+                        p_cR[pos] = wr * wa * wb * M;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- bin owners consume their cells' lists in order
+#pragma unroll
+            for (int u = 0; u < BPL; ++u) {
+                if (u > 0 && my_cell[u] == my_cell[u - 1]) continue;   // handled with bin u-1
+                if (my_cell[u] < 0) continue;
+                const int e1 = cstart[my_cell[u] + 1];
+                for (int e = cstart[my_cell[u]]; e < e1; ++e) {
+                    const int kk = p_k[e];
+                    const double vL = p_cL[e], vR = p_cR[e];
+#pragma unroll
+                    for (int v = u; v < BPL; ++v) {
+                        if (my_cell[v] != my_cell[u]) break;
+                        if (kk == my_k[v]) acc[v] = (float)((double)acc[v] + vL);
+                        else if (kk == my_kprev[v]) acc[v] = (float)((double)acc[v] + vR);
+                    }
+                }
+            }
+            // ---- pop the processed samples from the queue
+            const int rem = qn - nproc;
+            int moved = 0;
+            if (lane < rem) moved = q_pix[nproc + lane];
+            __syncthreads();
+            if (lane < rem) q_pix[lane] = moved;
+            qn = rem;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < BPL; ++u)
+            if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
+        __syncthreads();
+        // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
+        if (lane == 0) {
+            float l2 = 0.f;
+            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
+            norm_s = (float)sqrt((double)l2);
+        }
+        __syncthreads();
+        const float cap = __fmul_rn(0.2f, norm_s);
+#pragma unroll
+        for (int u = 0; u < BPL; ++u) {
+            acc[u] = fminf(acc[u], cap);
+            if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            float l2 = 0.f;
+            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
+            norm_s = (float)sqrt((double)l2);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BPL; ++u) {
+            const int t = lane * BPL + u;
+            if (t < nd) {
+                float v = (float)(int)((double)acc[u] * 512.0 / (double)norm_s);
+                v = v < 255.f ? v : 255.f;
+                if (out_descr) out_descr[(b * kcap + q) * SA_MAX_DESCR + t] = v;
+                if (out_std && t < 128) out_std[b * kcap + q].descriptor[t] = (unsigned char)v;
+            }
+        }
+        if (out_std && lane == 0) {
+            SaStd* o = &out_std[b * kcap + q];
+            o->x = key.x; o->y = key.y; o->scale = key.sigma; o->orientation = key.theta;
+        }
+        __syncthreads();
+    }
+}
+
 // ================================================================ launchers ==
 #define HIPK(...) do { hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
@@ -1053,10 +1278,16 @@ static void blur_h_t(hipStream_t st, const BlurArgs& a)
 template <int R>
 static void blur_fused_t(hipStream_t st, const BlurArgs& a)
 {
-    const int strip = 128;
-    dim3 grid((a.w + 223) / 224, (a.h + strip - 1) / strip, a.batch);
-    HIPK(k_blur_fused<R>, grid, dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
-         a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip);
+    // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
+    // sequentially, so small octaves get short strips to keep >= ~2000 blocks in flight
+    static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
+    int strip = 128;
+    const long long cols = (a.w + 223) / 224;
+    while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch < 2048) strip >>= 1;
+    if (forced > 0) strip = forced;
+    const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
+    HIPK(k_blur_fused<R>, dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+         a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks);
 }
 
 // Single-kernel blur (column + row pass, DoG and optional subsample epilogue).
@@ -1179,6 +1410,18 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
                        const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
                        int batch)
 {
+    static const bool block_form = getenv("SIFT_AMD_DESCR") && !strcmp(getenv("SIFT_AMD_DESCR"), "block");
+    const int nd = sc.n_hist * sc.n_hist * sc.n_ori;
+    if (!block_form) {
+        const dim3 grid(4096, batch), blk(64);
+        switch ((nd + 63) / 64) {
+            case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+            case 2: HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+            case 3: HIPK(k_descriptor_wave<3>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+            default: HIPK(k_descriptor_wave<4>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+        }
+        return;
+    }
     if (sc.n_hist * sc.n_hist * sc.n_ori <= 128)
         HIPK(k_descriptor<128>, dim3(2048, batch), dim3(128), 0, st, P, sc, keys, counters, cnt_slot, kcap,
              out_std, out_descr);

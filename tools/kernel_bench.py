@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-kernel-class event timings of the pipeline (library timers) for quick A/B runs.
+
+    python tools/kernel_bench.py [--w 1920 --h 1080 --batch 16 --iters 10 --kind smooth]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import sift_amd  # noqa: E402
+from sift_amd import api, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--kind", default="smooth")
+    a = ap.parse_args()
+    imgs = np.stack([synth.make(a.kind, a.w, a.h, 12345 + b) for b in range(min(a.batch, 4))])
+    imgs = np.concatenate([imgs] * ((a.batch + len(imgs) - 1) // len(imgs)))[:a.batch]
+    d = torch.from_numpy(imgs).cuda()
+    ctx = sift_amd.Context(a.w, a.h, a.batch)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):
+        ctx.detect_device(d.data_ptr(), a.batch, st)
+        ctx.counts()
+    ctx.profile_enable(list(range(api.K_COUNT)))
+    for c in range(api.K_COUNT):
+        ctx.profile_read(c, -1, reset=True)
+    for _ in range(a.iters):
+        ctx.detect_device(d.data_ptr(), a.batch, st)
+        ctx.counts()
+    tot = 0.0
+    for c in range(api.K_COUNT):
+        ms, n = ctx.profile_read(c, -1)
+        if not n:
+            continue
+        per_oct = []
+        for o in range(ctx.n_oct):
+            m, k = ctx.profile_read(c, o)
+            if k:
+                per_oct.append(f"o{o}:{m / a.iters:.3f}")
+        tot += ms / a.iters
+        print(f"{api.KERNEL_CLASSES[c]:12s} {ms / a.iters:8.3f} ms/iter  ({n // a.iters} launches)  " + " ".join(per_oct))
+    print(f"sum {tot:.3f} ms/iter for {a.batch} images -> {tot / a.batch * 1e3:.1f} us/image")
+
+
+if __name__ == "__main__":
+    main()
