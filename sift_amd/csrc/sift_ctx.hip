@@ -160,6 +160,16 @@ struct sift_amd_ctx {
     bool counters_valid = false;
     std::vector<void*> allocs;
 
+    // cached hipGraphs of the whole launch sequence, keyed by (input pointer, batch, timers)
+    struct GraphEntry {
+        const float* d_images; int n; unsigned prof_mask; int what;
+        hipGraphExec_t exec; std::vector<ProfEvent> events;
+    };
+    bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
+    std::vector<GraphEntry*> graphs;
+    GraphEntry* capturing = nullptr;
+    hipStream_t capture_stream = nullptr;
+
     unsigned prof_mask = 0;
     std::vector<ProfEvent> prof_pending;
     std::vector<hipEvent_t> prof_pool;
@@ -235,6 +245,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     c->p = *p; c->L = *L; c->sigma_in = sigma_in;
     auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
     if (const char* m = getenv("SIFT_AMD_BLUR")) c->fused_blur = strcmp(m, "split") != 0;
+    if (const char* m = getenv("SIFT_AMD_GRAPH")) c->use_graph = atoi(m) != 0;
 
     for (int o = 1; o < L->n_oct; o++)
         if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
@@ -242,7 +253,8 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
             return fail();
         }
 
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) {
         sa_set_error("hipStreamCreate failed");
         return fail();
     }
@@ -339,6 +351,12 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
     hipDeviceSynchronize();
     for (auto& e : c->prof_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : c->prof_pool) hipEventDestroy(e);
+    for (auto* g : c->graphs) {
+        for (auto& e : g->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+        if (g->exec) hipGraphExecDestroy(g->exec);
+        delete g;
+    }
+    if (c->capture_stream) hipStreamDestroy(c->capture_stream);
     for (void* v : c->allocs) hipFree(v);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -387,6 +405,7 @@ struct ProfScope {
 
 static void prof_collect(sift_amd_ctx* c)
 {
+
     for (auto& e : c->prof_pending) {
         float ms = 0.f;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
@@ -418,9 +437,11 @@ extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, doubl
 // ---------------------------------------------------------------- pipeline --
 
 static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
-                     float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n)
+                     float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n,
+                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f)
 {
     sa::BlurArgs a;
+    a.ovs_w = ovs_w; a.ovs_h = ovs_h; a.ovs_delta = ovs_delta;
     a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog; a.sub = sub;
     a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog; a.s_sub = s_sub;
     a.w = c->L.w[o]; a.h = c->L.h[o]; a.batch = n;
@@ -448,7 +469,12 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
         float* g = c->d_gss[o];
         float* d = c->d_dog[o];
         if (o == 0) {
-            if (L.delta[0] < 1.f) {
+            const bool fuse_ovs = c->fused_blur && c->seed.radius >= 1 && c->seed.radius <= SA_MAX_RADIUS_FAST;
+            if (L.delta[0] < 1.f && fuse_ovs) {
+                // oversampling evaluated inside the seed blur's loads: no oversampled image in memory
+                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n,
+                         c->im_w, c->im_h, L.delta[0]);
+            } else if (L.delta[0] < 1.f) {
                 { ProfScope ps(c, st, SIFT_AMD_K_OVERSAMPLE, 0);
                   sa::launch_oversample(st, d_images, c->im_w, c->im_h, (long long)c->im_w * c->im_h,
                                         c->d_seed, L.w[0], L.h[0], np, L.delta[0], n); }
@@ -534,21 +560,70 @@ static int begin_run(sift_amd_ctx* c, int n, hipStream_t st)
     return 0;
 }
 
+// what: 0 = scale-space only, 1 = whole pipeline
+static int run_sequence(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, int what)
+{
+    if (sa_run_scalespace(c, d_images, n, st)) return -1;
+    if (what == 0) return 0;
+    if (sa_run_detect(c, n, st)) return -1;
+    if (sa_run_orient(c, n, st, false, 0)) return -1;
+    return sa_run_describe(c, n, st);
+}
+
+// The launch sequence of a batch is ~70 short dependent launches; replaying it as a hipGraph
+// removes the host launch cost between them.  Graphs are cached per (input pointer, batch size,
+// timer mask); anything that cannot be captured falls back to plain launches.
+static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, int what)
+{
+    // event timers cannot be read back from captured event nodes: timed runs launch eagerly
+    if (!c->use_graph || c->prof_mask) return run_sequence(c, d_images, n, st, what);
+    sift_amd_ctx::GraphEntry* g = nullptr;
+    for (auto* e : c->graphs)
+        if (e->d_images == d_images && e->n == n && e->prof_mask == c->prof_mask && e->what == what) { g = e; break; }
+    if (!g) {
+        if (c->graphs.size() >= 8) {   // drop the oldest entry
+            auto* old = c->graphs.front();
+            c->graphs.erase(c->graphs.begin());
+            for (auto& e : old->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+            if (old->exec) hipGraphExecDestroy(old->exec);
+            delete old;
+        }
+        g = new sift_amd_ctx::GraphEntry{d_images, n, c->prof_mask, what, nullptr, {}};
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(c->capture_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            c->capturing = g;
+            const int rc = run_sequence(c, d_images, n, c->capture_stream, what);
+            c->capturing = nullptr;
+            ok = hipStreamEndCapture(c->capture_stream, &graph) == hipSuccess && rc == 0 && graph;
+        }
+        if (ok) ok = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) {
+            (void)hipGetLastError();
+            for (auto& e : g->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+            delete g;
+            c->use_graph = false;
+            return run_sequence(c, d_images, n, st, what);
+        }
+        c->graphs.push_back(g);
+    }
+    HIP_TRY(hipGraphLaunch(g->exec, st));
+    return 0;
+}
+
 extern "C" int sift_amd_scalespace_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
 {
     hipStream_t st = pick_stream(c, stream);
     if (begin_run(c, n, st)) return -1;
-    return sa_run_scalespace(c, d_images, n, st);
+    return run_graphed(c, d_images, n, st, 0);
 }
 
 extern "C" int sift_amd_detect_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
 {
     hipStream_t st = pick_stream(c, stream);
     if (begin_run(c, n, st)) return -1;
-    if (sa_run_scalespace(c, d_images, n, st)) return -1;
-    if (sa_run_detect(c, n, st)) return -1;
-    if (sa_run_orient(c, n, st, false, 0)) return -1;
-    return sa_run_describe(c, n, st);
+    return run_graphed(c, d_images, n, st, 1);
 }
 
 extern "C" int sift_amd_detect_host(sift_amd_ctx* c, const float* images, int n)

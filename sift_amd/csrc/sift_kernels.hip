@@ -239,11 +239,32 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
 // order per output is identical to the two-kernel form, so results are bit-identical.
 // `sub`, if given, receives the even samples (the next octave's first image,
 // lib_discrete.c:180-191).
-template <int R>
+// Source sample (i, col) of the fused blur when the source is the bilinearly oversampled
+// input (OVS): same expression and operation order as k_oversample / lib_discrete.c:207-237.
+struct OvsCol { int jm, jp; float fy; };
+__device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int wi, int hi, float delta,
+                                            int i, const OvsCol& c)
+{
+    const float x = i * delta;
+    int im = (int)x, ip = im + 1;
+    if (ip >= hi) ip = 2 * hi - 1 - ip;
+    if (im >= hi) im = 2 * hi - 1 - im;
+    const float fx = x - floorf(x);
+    const float a = img[(long long)ip * wi + c.jp], b = img[(long long)ip * wi + c.jm];
+    const float cc = img[(long long)im * wi + c.jp], d = img[(long long)im * wi + c.jm];
+    const float top = __fadd_rn(__fmul_rn(c.fy, a), __fmul_rn(1 - c.fy, b));
+    const float bot = __fadd_rn(__fmul_rn(c.fy, cc), __fmul_rn(1 - c.fy, d));
+    return __fadd_rn(__fmul_rn(fx, top), __fmul_rn(1 - fx, bot));
+}
+
+// OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
+// version at step `delta`, evaluated on the fly (w x h is the oversampled size).
+template <int R, bool OVS>
 __global__ void __launch_bounds__(256)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
-             long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks)
+             long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks,
+             int wi, int hi, float delta)
 {
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
     // the row pass free of bank conflicts also where a wave straddles two rows.
@@ -259,7 +280,21 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const int bx = vid % nbx, by = (vid / nbx) % nby;
     const long long b = vid / (nbx * nby);
     const int x0 = bx * TW;
-    const float* src = in + b * s_in + mirror_idx(x0 - RP + tid, w);
+    const int col = mirror_idx(x0 - RP + tid, w);
+    const float* src = in + b * s_in + (OVS ? 0 : col);
+    OvsCol oc;
+    if (OVS) {
+        const float y = col * delta;
+        oc.jm = (int)y; oc.jp = oc.jm + 1;
+        if (oc.jp >= wi) oc.jp = 2 * wi - 1 - oc.jp;
+        if (oc.jm >= wi) oc.jm = 2 * wi - 1 - oc.jm;
+        oc.fy = y - floorf(y);
+    }
+    auto load = [&](int i) -> float {
+        const int r = mirror_idx(i, h);
+        if (OVS) return ovs_sample(src, wi, hi, delta, r, oc);
+        return src[(long long)r * w];
+    };
     const int i0 = by * strip;
     const int i1 = min(i0 + strip, h);
     const bool vec_w = (w & 3) == 0;
@@ -268,9 +303,9 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     float win[G + 2 * R];
     float nx[G];
 #pragma unroll
-    for (int t = 0; t < 2 * R; ++t) win[t] = src[(long long)mirror_idx(i0 - R + t, h) * w];
+    for (int t = 0; t < 2 * R; ++t) win[t] = load(i0 - R + t);
 #pragma unroll
-    for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(i0 + R + g, h) * w];
+    for (int g = 0; g < G; ++g) nx[g] = load(i0 + R + g);
 
     int buf = 0;
     for (int ii = i0; ii < i1; ii += G, buf ^= (SA_BLUR_NBUF - 1)) {
@@ -278,7 +313,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
         if (ii + G < i1) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(ii + G + R + g, h) * w];
+            for (int g = 0; g < G; ++g) nx[g] = load(ii + G + R + g);
         }
         if (SA_BLUR_NBUF == 1) __syncthreads();
 #pragma unroll
@@ -433,13 +468,20 @@ struct ExtWin {
     float C[NDOG - 2][3], EM[NDOG - 2][3], Em[NDOG - 2][3];  // centre, max/min of (left,right)
 };
 
+template <int NDOG>
+__device__ __forceinline__ void ext_fetch(float (&raw)[NDOG], const float* __restrict__ base,
+                                          long long img_n, long long off)
+{
+#pragma unroll
+    for (int d = 0; d < NDOG; ++d) raw[d] = base[d * img_n + off];
+}
+
 template <int NDOG, int SLOT>
-__device__ __forceinline__ void ext_load(ExtWin<NDOG>& W, const float* __restrict__ base,
-                                         long long img_n, long long off)
+__device__ __forceinline__ void ext_load(ExtWin<NDOG>& W, const float (&raw)[NDOG])
 {
 #pragma unroll
     for (int d = 0; d < NDOG; ++d) {
-        const float v = base[d * img_n + off];
+        const float v = raw[d];
         const float l = lane_prev(v), r = lane_next(v);
         W.M3[d][SLOT] = max3f(l, v, r);
         W.N3[d][SLOT] = min3f(l, v, r);
@@ -517,17 +559,38 @@ k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
 
     ExtWin<NDOG> W;
     int n_ext = 0;
-    ext_load<NDOG, 0>(W, base, img_n, (long long)(ibeg - 1) * w);
-    ext_load<NDOG, 1>(W, base, img_n, (long long)ibeg * w);
+    // rows are fetched two steps ahead of their use so that two rows of loads are in flight
+    float rawA[NDOG], rawB[NDOG];
+    ext_fetch<NDOG>(rawA, base, img_n, (long long)(ibeg - 1) * w);
+    ext_fetch<NDOG>(rawB, base, img_n, (long long)ibeg * w);
+    ext_load<NDOG, 0>(W, rawA);
+    ext_fetch<NDOG>(rawA, base, img_n, (long long)min(ibeg + 1, h - 1) * w);
+    ext_load<NDOG, 1>(W, rawB);
     int i = ibeg;
+    // invariant at the top of each step: rawA/rawB (alternating) holds row i+1
     while (true) {
-        ext_load<NDOG, 2>(W, base, img_n, (long long)(i + 1) * w);
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 2>(W, rawA);
         ext_eval<NDOG, 0, 1, 2>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_load<NDOG, 0>(W, base, img_n, (long long)(i + 1) * w);
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 0>(W, rawB);
         ext_eval<NDOG, 1, 2, 0>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_load<NDOG, 1>(W, base, img_n, (long long)(i + 1) * w);
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 1>(W, rawA);
+        ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 2>(W, rawB);
+        ext_eval<NDOG, 0, 1, 2>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 0>(W, rawA);
+        ext_eval<NDOG, 1, 2, 0>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+        if (++i >= iend) break;
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_load<NDOG, 1>(W, rawB);
         ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
     }
@@ -1286,8 +1349,12 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch < 2048) strip >>= 1;
     if (forced > 0) strip = forced;
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
-    HIPK(k_blur_fused<R>, dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
-         a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks);
+    if (a.ovs_w > 0)
+        HIPK((k_blur_fused<R, true>), dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta);
+    else
+        HIPK((k_blur_fused<R, false>), dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, 0, 0, 0.f);
 }
 
 // Single-kernel blur (column + row pass, DoG and optional subsample epilogue).

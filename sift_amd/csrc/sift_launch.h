@@ -19,6 +19,10 @@ struct BlurArgs {
     int radius;
     SaTaps taps;             // radius <= SA_MAX_RADIUS_FAST
     const float* taps_dev;   // radius+1 taps in device memory (any radius)
+    // fused kernel only: if ovs_w > 0, `in` is the ovs_w x ovs_h input image and the source of
+    // the blur is its bilinear oversampling at step ovs_delta (w x h = oversampled size)
+    int ovs_w = 0, ovs_h = 0;
+    float ovs_delta = 0.f;
 };
 
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
