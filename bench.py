@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--kind", default="smooth", choices=["smooth", "white"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="contexts/streams used alternately (1 = strictly one batch at a time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +113,27 @@ def main():
     host = np.stack([synth.make(args.kind, W_IM, H_IM, seed=12345 + rank * B + b) for b in range(B)])
     d_imgs = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = sift_amd.Context(W_IM, H_IM, max_batch=B, device=local_rank)
+    # Two contexts (two pyramid pools) on two streams, used alternately: the latency-bound tail of
+    # one batch (orientation, descriptors, host gather) overlaps the bandwidth-bound scale-space of
+    # the next.  Both batches read the same resident input images.
+    n_ctx = max(1, args.pipeline)
+    ctxs = [sift_amd.Context(W_IM, H_IM, max_batch=B, device=local_rank) for _ in range(n_ctx)]
+    streams = [torch.cuda.Stream() for _ in range(n_ctx)]
+    ctx = ctxs[0]
+
+    def run_steps(n_steps):
+        """Queues n_steps batches; the gather of batch i is issued after batch i+1 is queued."""
+        last = None
+        pending = []
+        for i in range(n_steps):
+            k = i % n_ctx
+            if len(pending) == n_ctx:
+                last = pending.pop(0).gather()
+            ctxs[k].detect_device(d_imgs.data_ptr(), B, streams[k].cuda_stream)
+            pending.append(ctxs[k])
+        for c in pending:
+            last = c.gather()
+        return last
 
     def step():
         ctx.detect_device(d_imgs.data_ptr(), B, stream)
@@ -122,12 +144,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        keys, counts = step()
+    keys, counts = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -191,6 +211,7 @@ def main():
                             "keypoints gathered to host memory inside the timed region",
                 "image": "1920x1080",
                 "batch_per_gpu": B,
+                "batches_in_flight": n_ctx,
                 "octaves": ctx.n_oct,
                 "keypoints_per_image": float(nk.item()) / (B * world),
                 "sharding": "by image, no collective on the data path",
@@ -212,7 +233,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

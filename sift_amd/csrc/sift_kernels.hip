@@ -268,7 +268,10 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 {
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
     // the row pass free of bank conflicts also where a wave straddles two rows.
-    constexpr int G = 8, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
+#ifndef SA_BLUR_G
+#define SA_BLUR_G 8
+#endif
+    constexpr int G = SA_BLUR_G, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
     constexpr int ITEMS = G * NG;
 #ifndef SA_BLUR_NBUF
 #define SA_BLUR_NBUF 2

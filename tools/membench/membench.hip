@@ -78,6 +78,32 @@ __global__ void k_r1w2_chunk(const float4* __restrict__ a, float4* __restrict__ 
     }
 }
 
+// tile-shaped traffic like the blur kernel: block = TWx(strip) tile of a WxH image, 8 rows per step,
+// reads 1 float per (thread, row) with dword loads, writes two float4 streams
+template <int TW>
+__global__ void k_tile_r1w2(const float* __restrict__ a, float* __restrict__ o1, float* __restrict__ o2,
+                            int w, int h, int strip, int nbx, int nby, int do_read)
+{
+    const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby;
+    const long long img = (long long)(blockIdx.x / (nbx * nby)) * w * h;
+    const int x0 = bx * TW, i0 = by * strip, i1 = min(i0 + strip, h);
+    const int tid = threadIdx.x;
+    for (int ii = i0; ii < i1; ii += 8) {
+        float acc = 0.f;
+        if (do_read)
+            for (int g = 0; g < 8; ++g) { int x = min(x0 + tid, w - 1); acc += a[img + (long long)min(ii + g, h - 1) * w + x]; }
+        for (int item = tid; item < 8 * (TW / 4); item += blockDim.x) {
+            const int g = item / (TW / 4), q = item % (TW / 4);
+            const int row = ii + g, x = x0 + 4 * q;
+            if (row < i1 && x + 4 <= w) {
+                const long long off = img + (long long)row * w + x;
+                *(float4*)(o1 + off) = make_float4(acc, 1.f, 2.f, 3.f);
+                *(float4*)(o2 + off) = make_float4(acc, 2.f, 2.f, 3.f);
+            }
+        }
+    }
+}
+
 template <typename F>
 static void timeit(const char* name, double bytes, F f)
 {
@@ -115,5 +141,21 @@ int main()
         timeit("r1 w2 float4 chunked", n * 12.0, [&] { k_r1w2_chunk<<<(unsigned)((n / 4 + pb - 1) / pb), 256>>>((float4*)a, (float4*)b, (float4*)c, n / 4, pb); });
     for (int g : {1024, 2048, 8192, 32768})
         timeit("r1 w2 float4 grid sweep", n * 12.0, [&] { k_r1w2<<<g, 256>>>((float4*)a, (float4*)b, (float4*)c, n / 4); });
+    {
+        const int w = 3840, h = 2160, B = 16;
+        for (int strip : {64, 128, 2160}) {
+            { const int nbx = (w + 223) / 224, nby = (h + strip - 1) / strip;
+              char nm[64]; snprintf(nm, 64, "tile 224 strip %d r1w2", strip);
+              timeit(nm, n * 12.0, [&] { k_tile_r1w2<224><<<nbx * nby * B, 256>>>(a, b, c, w, h, strip, nbx, nby, 1); });
+              snprintf(nm, 64, "tile 224 strip %d w2 only", strip);
+              timeit(nm, n * 8.0, [&] { k_tile_r1w2<224><<<nbx * nby * B, 256>>>(a, b, c, w, h, strip, nbx, nby, 0); }); }
+            { const int nbx = (w + 255) / 256, nby = (h + strip - 1) / strip;
+              char nm[64]; snprintf(nm, 64, "tile 256 strip %d r1w2", strip);
+              timeit(nm, n * 12.0, [&] { k_tile_r1w2<256><<<nbx * nby * B, 256>>>(a, b, c, w, h, strip, nbx, nby, 1); }); }
+            { const int nbx = (w + 959) / 960, nby = (h + strip - 1) / strip;
+              char nm[64]; snprintf(nm, 64, "tile 960 strip %d w2 only", strip);
+              timeit(nm, n * 8.0, [&] { k_tile_r1w2<960><<<nbx * nby * B, 256>>>(a, b, c, w, h, strip, nbx, nby, 0); }); }
+        }
+    }
     return 0;
 }
