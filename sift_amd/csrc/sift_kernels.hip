@@ -1434,8 +1434,13 @@ int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int
                    int* counters, int cap, int batch)
 {
     if (w < 3 || h < 3) return 0;
-    const int rpw = 32;
+    static const int forced = getenv("SIFT_AMD_EXT_RPW") ? atoi(getenv("SIFT_AMD_EXT_RPW")) : 0;
     const int nseg = (w - 2 + 61) / 62;
+    // tall strips amortise the two halo rows and keep a wave's loads streaming; small octaves
+    // need short strips to have enough waves in flight
+    int rpw = 128;
+    while (rpw > 16 && (long long)nseg * ((h - 2 + rpw - 1) / rpw) * batch < 2500) rpw >>= 1;
+    if (forced > 0) rpw = forced;
     dim3 grid((nseg + 3) / 4, (h - 2 + rpw - 1) / rpw, batch);
 #define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap)
     switch (n_dog) {

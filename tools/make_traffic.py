@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Builds profiles/traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_passes.sh.
+
+HBM bytes per launch of the dominant kernel (the octave-0 blur launches), corrected as the
+MI355X counter notes prescribe: FETCH_SIZE (KiB) counts half of the bytes of coalesced streaming
+reads on gfx950 (checked on this machine with tools/membench: dword and float4 reads of a known
+size both report exactly 1/2), WRITE_SIZE (KiB) is exact.
+
+    python tools/make_traffic.py gpurun_out/<tag> <blocks-of-the-octave-0-launch> [out.json]
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def per_launch(tag, name, counter, kernel_substr, grid_threads):
+    path = glob.glob(f"{tag}/{name}/**/*counter_collection.csv", recursive=True)[0]
+    per_dispatch = collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) == grid_threads:
+            per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    vals = list(per_dispatch.values())
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    tag, blocks = sys.argv[1], int(sys.argv[2])
+    out = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
+    grid = blocks * 256
+    fetch_kib, n1 = per_launch(tag, "fetch", "FETCH_SIZE", "k_blur_fused", grid)
+    write_kib, n2 = per_launch(tag, "write", "WRITE_SIZE", "k_blur_fused", grid)
+    rd, wr = 2.0 * fetch_kib * 1024, write_kib * 1024
+    rec = {"kernel": "k_blur_fused, octave 0 launches", "launches_sampled": [n1, n2],
+           "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
+           "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+           "bytes_per_launch": rd + wr,
+           "correction": "read = 2 x FETCH_SIZE KiB (gfx950 counts 64 B per 128 B request), write = WRITE_SIZE KiB",
+           "source": tag}
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
