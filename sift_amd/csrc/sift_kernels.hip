@@ -17,6 +17,16 @@
 #include "sift_dev.h"
 #include "sift_launch.h"
 
+// Native 4-float vector: 16-byte LDS/global accesses compile to single b128 / dwordx4
+// instructions (HIP's float4 struct gets split into narrower accesses).
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(__builtin_assume_aligned(p, 16)); }
+__device__ __forceinline__ void st4(float* p, float a, float b, float c, float d)
+{
+    v4f v = {a, b, c, d};
+    *reinterpret_cast<v4f*>(__builtin_assume_aligned(p, 16)) = v;
+}
+
 #define SA_PI 3.14159265358979323846
 #define SA_SQRT2 1.41421356237309504880
 
@@ -176,11 +186,11 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
         if (active) {
             const float* srow = src + (long long)row * w;
             if (fast) {
-                const float4 a = *reinterpret_cast<const float4*>(srow + x0 - RP + 4 * lane);
-                *reinterpret_cast<float4*>(row_lds + 4 * lane) = a;
+                const v4f a = ld4(srow + x0 - RP + 4 * lane);
+                *reinterpret_cast<v4f*>(row_lds + 4 * lane) = a;
                 if (lane < (LW - TW) / 4) {
-                    const float4 c = *reinterpret_cast<const float4*>(srow + x0 - RP + TW + 4 * lane);
-                    *reinterpret_cast<float4*>(row_lds + TW + 4 * lane) = c;
+                    const v4f c = ld4(srow + x0 - RP + TW + 4 * lane);
+                    *reinterpret_cast<v4f*>(row_lds + TW + 4 * lane) = c;
                 }
             } else {
                 for (int t = lane; t < LW; t += 64) row_lds[t] = srow[mirror_idx(x0 - RP + t, w)];
@@ -191,7 +201,7 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
             float win[4 + 2 * RP];
 #pragma unroll
             for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(row_lds + 4 * lane + 4 * q);
+                const v4f v = ld4(row_lds + 4 * lane + 4 * q);
                 win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
             }
             float o4[4];
@@ -206,12 +216,11 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
             const int x = x0 + 4 * lane;
             const long long off = (long long)row * w + x;
             if (fast) {
-                *reinterpret_cast<float4*>(out + b * s_out + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                st4(out + b * s_out + off, o4[0], o4[1], o4[2], o4[3]);
                 if (dog) {
-                    const float4 p = *reinterpret_cast<const float4*>(prev + b * s_prev + off);
-                    *reinterpret_cast<float4*>(dog + b * s_dog + off) =
-                        make_float4(__fsub_rn(o4[0], p.x), __fsub_rn(o4[1], p.y),
-                                    __fsub_rn(o4[2], p.z), __fsub_rn(o4[3], p.w));
+                    const v4f p = ld4(prev + b * s_prev + off);
+                    st4(dog + b * s_dog + off, __fsub_rn(o4[0], p.x), __fsub_rn(o4[1], p.y),
+                        __fsub_rn(o4[2], p.z), __fsub_rn(o4[3], p.w));
                 }
             } else {
 #pragma unroll
@@ -259,8 +268,8 @@ __device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int w
 
 // OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
 // version at step `delta`, evaluated on the fly (w x h is the oversampled size).
-template <int R, bool OVS>
-__global__ void __launch_bounds__(256)
+template <int R, bool OVS, int EW, int NBUF>
+__global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
              long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks,
@@ -268,16 +277,10 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 {
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
     // the row pass free of bank conflicts also where a wave straddles two rows.
-#ifndef SA_BLUR_G
-#define SA_BLUR_G 8
-#endif
-    constexpr int G = SA_BLUR_G, RP = 16, EW = 256, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
+    constexpr int G = 8, RP = 16, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
     constexpr int ITEMS = G * NG;
-#ifndef SA_BLUR_NBUF
-#define SA_BLUR_NBUF 2
-#endif
-    __shared__ __attribute__((aligned(16))) float l_tmp[SA_BLUR_NBUF][G][PITCH];
-    __shared__ __attribute__((aligned(16))) float l_prev[SA_BLUR_NBUF][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float l_tmp[NBUF][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float l_prev[NBUF][G][PITCH];
     const int tid = threadIdx.x;
     const unsigned vid = xcd_remap(blockIdx.x, nblocks);
     const int bx = vid % nbx, by = (vid / nbx) % nby;
@@ -303,22 +306,25 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const bool vec_w = (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
 
+    // Source rows are fetched two iterations (16 rows) ahead of their use.
     float win[G + 2 * R];
-    float nx[G];
+    float nx[G], nx2[G];
 #pragma unroll
     for (int t = 0; t < 2 * R; ++t) win[t] = load(i0 - R + t);
 #pragma unroll
     for (int g = 0; g < G; ++g) nx[g] = load(i0 + R + g);
+#pragma unroll
+    for (int g = 0; g < G; ++g) nx2[g] = load(i0 + G + R + g);
 
     int buf = 0;
-    for (int ii = i0; ii < i1; ii += G, buf ^= (SA_BLUR_NBUF - 1)) {
+    for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
-        if (ii + G < i1) {
+        for (int g = 0; g < G; ++g) { win[2 * R + g] = nx[g]; nx[g] = nx2[g]; }
+        if (ii + 2 * G < i1) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) nx[g] = load(ii + G + R + g);
+            for (int g = 0; g < G; ++g) nx2[g] = load(ii + 2 * G + R + g);
         }
-        if (SA_BLUR_NBUF == 1) __syncthreads();
+        if (NBUF == 1) __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float s = __fmul_rn(win[g + R], tp.g[0]);
@@ -330,8 +336,8 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         }
         __syncthreads();
 #pragma unroll
-        for (int rnd = 0; rnd < (ITEMS + 255) / 256; ++rnd) {
-            const int item = rnd * 256 + tid;
+        for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
+            const int item = rnd * EW + tid;
             const int hg = item / NG, hq = item - hg * NG;
             const int row = ii + hg, xo = x0 + 4 * hq;
             if (item < ITEMS && row < i1 && xo < w) {
@@ -339,7 +345,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 const float* lrow = &l_tmp[buf][hg][4 * hq];
 #pragma unroll
                 for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(lrow + 4 * q);
+                    const v4f v = ld4(lrow + 4 * q);
                     hw[4 * q + 0] = v.x; hw[4 * q + 1] = v.y; hw[4 * q + 2] = v.z; hw[4 * q + 3] = v.w;
                 }
                 float o4[4];
@@ -355,19 +361,19 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 const long long off = (long long)row * w + xo;
                 float* po = out + b * s_out + off;
                 if (vec) {
-                    *reinterpret_cast<float4*>(po) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                    st4(po, o4[0], o4[1], o4[2], o4[3]);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (xo + q < w) po[q] = o4[q];
                 }
                 if (dog) {
-                    const float4 pv = *reinterpret_cast<const float4*>(&l_prev[buf][hg][RP + 4 * hq]);
+                    const v4f pv = ld4(&l_prev[buf][hg][RP + 4 * hq]);
                     float* pd = dog + b * s_dog + off;
                     const float d4[4] = {__fsub_rn(o4[0], pv.x), __fsub_rn(o4[1], pv.y),
                                          __fsub_rn(o4[2], pv.z), __fsub_rn(o4[3], pv.w)};
                     if (vec) {
-                        *reinterpret_cast<float4*>(pd) = make_float4(d4[0], d4[1], d4[2], d4[3]);
+                        st4(pd, d4[0], d4[1], d4[2], d4[3]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -1341,23 +1347,33 @@ static void blur_h_t(hipStream_t st, const BlurArgs& a)
     case 9: F(9); break; case 10: F(10); break; case 11: F(11); break; case 12: F(12); break; \
     case 13: F(13); break; case 14: F(14); break; case 15: F(15); break; case 16: F(16); break;
 
-template <int R>
-static void blur_fused_t(hipStream_t st, const BlurArgs& a)
+template <int R, int EW, int NBUF>
+static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
 {
+    constexpr int TW = EW - 32;
     // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
-    // sequentially, so small octaves get short strips to keep >= ~2000 blocks in flight
+    // sequentially, so small octaves get short strips to keep enough blocks in flight
     static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
-    int strip = 128;
-    const long long cols = (a.w + 223) / 224;
-    while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch < 2048) strip >>= 1;
+    int strip = EW == 512 ? 256 : 128;
+    const long long cols = (a.w + TW - 1) / TW;
+    while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (forced > 0) strip = forced;
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
     if (a.ovs_w > 0)
-        HIPK((k_blur_fused<R, true>), dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+        HIPK((k_blur_fused<R, true, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
              a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta);
     else
-        HIPK((k_blur_fused<R, false>), dim3(nblocks), dim3(256), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
+        HIPK((k_blur_fused<R, false, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
              a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, 0, 0, 0.f);
+}
+
+template <int R>
+static void blur_fused_t(hipStream_t st, const BlurArgs& a)
+{
+    // wide tiles (480 outputs of 512 columns) halve the column halo; worth it on wide images
+    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 1 << 30;
+    if (a.w >= wide_min) blur_fused_launch<R, 512, 1>(st, a);
+    else blur_fused_launch<R, 256, 2>(st, a);
 }
 
 // Single-kernel blur (column + row pass, DoG and optional subsample epilogue).

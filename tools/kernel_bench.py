@@ -23,11 +23,17 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--kind", default="smooth")
+    ap.add_argument("--sigma-min", type=float, default=0.8)
+    ap.add_argument("--sigma-in", type=float, default=0.5)
     a = ap.parse_args()
     imgs = np.stack([synth.make(a.kind, a.w, a.h, 12345 + b) for b in range(min(a.batch, 4))])
     imgs = np.concatenate([imgs] * ((a.batch + len(imgs) - 1) // len(imgs)))[:a.batch]
     d = torch.from_numpy(imgs).cuda()
-    ctx = sift_amd.Context(a.w, a.h, a.batch)
+    from sift_amd import abi
+    params = abi.SiftParameters.default().copy(sigma_min=a.sigma_min, sigma_in=a.sigma_in)
+    ctx = sift_amd.Context(a.w, a.h, a.batch, params)
+    g = ctx.geometry
+    print("octave-0 blur radii:", [g.blur_radius[0][s] for s in range(ctx.n_sca)])
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         ctx.detect_device(d.data_ptr(), a.batch, st)
