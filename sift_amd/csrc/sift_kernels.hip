@@ -306,23 +306,21 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const bool vec_w = (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
 
-    // Source rows are fetched two iterations (16 rows) ahead of their use.
+    // Source rows are fetched one iteration (8 rows) ahead of their use.
     float win[G + 2 * R];
-    float nx[G], nx2[G];
+    float nx[G];
 #pragma unroll
     for (int t = 0; t < 2 * R; ++t) win[t] = load(i0 - R + t);
 #pragma unroll
     for (int g = 0; g < G; ++g) nx[g] = load(i0 + R + g);
-#pragma unroll
-    for (int g = 0; g < G; ++g) nx2[g] = load(i0 + G + R + g);
 
     int buf = 0;
     for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) { win[2 * R + g] = nx[g]; nx[g] = nx2[g]; }
-        if (ii + 2 * G < i1) {
+        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
+        if (ii + G < i1) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) nx2[g] = load(ii + 2 * G + R + g);
+            for (int g = 0; g < G; ++g) nx[g] = load(ii + G + R + g);
         }
         if (NBUF == 1) __syncthreads();
 #pragma unroll
@@ -1354,7 +1352,7 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
     // sequentially, so small octaves get short strips to keep enough blocks in flight
     static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
-    int strip = EW == 512 ? 256 : 128;
+    int strip = EW == 512 ? 128 : 64;
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (forced > 0) strip = forced;
