@@ -57,11 +57,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned l, unsigned total)
 // lane i receives the value of lane i-1 / i+1 of the wave (edge lanes receive 0).
 __device__ __forceinline__ float lane_prev(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_next(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -477,10 +477,11 @@ struct ExtWin {
 
 template <int NDOG>
 __device__ __forceinline__ void ext_fetch(float (&raw)[NDOG], const float* __restrict__ base,
-                                          long long img_n, long long off)
+                                          long long img_n, long long off, int j)
 {
+    // base/img_n/off are wave-uniform, j is the lane's column: scalar base + 32-bit lane offset
 #pragma unroll
-    for (int d = 0; d < NDOG; ++d) raw[d] = base[d * img_n + off];
+    for (int d = 0; d < NDOG; ++d) raw[d] = (base + d * img_n + off)[j];
 }
 
 template <int NDOG, int SLOT>
@@ -547,18 +548,21 @@ __global__ void __launch_bounds__(256)
 k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
           float thr_pre, int emit_all, int rows_per_wave,
           unsigned long long* __restrict__ ckey, float* __restrict__ cval,
-          int* __restrict__ counters, int cap)
+          int* __restrict__ counters, int cap, int nbx, int nby, int nblocks)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * 4 + wave;
+    // column-adjacent blocks share cache lines at their boundary: keep them on one XCD
+    const unsigned vid = xcd_remap(blockIdx.x, nblocks);
+    const int bx = vid % nbx, by = (vid / nbx) % nby;
+    const long long b = vid / (nbx * nby);
+    const int seg = bx * 4 + wave;
     const int jraw = seg * 62 + lane;                // lane 1 of seg 0 is column 1
-    const long long b = blockIdx.z;
-    const int ibeg = blockIdx.y * rows_per_wave + 1;  // first output row of the strip
+    const int ibeg = by * rows_per_wave + 1;          // first output row of the strip
     const int iend = min(ibeg + rows_per_wave, h - 1);  // one past the last output row
     if (seg * 62 + 1 > w - 2 || ibeg >= iend) return;  // wave-uniform
     const int j = min(jraw, w - 1);
     const bool lane_ok = lane >= 1 && lane <= 62 && jraw <= w - 2;
-    const float* base = dog + b * s_dog + j;
+    const float* base = dog + b * s_dog;
     const long long img_n = (long long)w * h;
     unsigned long long* kb = ckey + b * cap;
     float* vb = cval + b * cap;
@@ -568,35 +572,35 @@ k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
     int n_ext = 0;
     // rows are fetched two steps ahead of their use so that two rows of loads are in flight
     float rawA[NDOG], rawB[NDOG];
-    ext_fetch<NDOG>(rawA, base, img_n, (long long)(ibeg - 1) * w);
-    ext_fetch<NDOG>(rawB, base, img_n, (long long)ibeg * w);
+    ext_fetch<NDOG>(rawA, base, img_n, (long long)(ibeg - 1) * w, j);
+    ext_fetch<NDOG>(rawB, base, img_n, (long long)ibeg * w, j);
     ext_load<NDOG, 0>(W, rawA);
-    ext_fetch<NDOG>(rawA, base, img_n, (long long)min(ibeg + 1, h - 1) * w);
+    ext_fetch<NDOG>(rawA, base, img_n, (long long)min(ibeg + 1, h - 1) * w, j);
     ext_load<NDOG, 1>(W, rawB);
     int i = ibeg;
     // invariant at the top of each step: rawA/rawB (alternating) holds row i+1
     while (true) {
-        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 2>(W, rawA);
         ext_eval<NDOG, 0, 1, 2>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 0>(W, rawB);
         ext_eval<NDOG, 1, 2, 0>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 1>(W, rawA);
         ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 2>(W, rawB);
         ext_eval<NDOG, 0, 1, 2>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawB, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 0>(W, rawA);
         ext_eval<NDOG, 1, 2, 0>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
-        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w);
+        ext_fetch<NDOG>(rawA, base, img_n, (long long)min(i + 2, h - 1) * w, j);
         ext_load<NDOG, 1>(W, rawB);
         ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
@@ -1455,8 +1459,9 @@ int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int
     int rpw = 128;
     while (rpw > 16 && (long long)nseg * ((h - 2 + rpw - 1) / rpw) * batch < 2500) rpw >>= 1;
     if (forced > 0) rpw = forced;
-    dim3 grid((nseg + 3) / 4, (h - 2 + rpw - 1) / rpw, batch);
-#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap)
+    const int nbx = (nseg + 3) / 4, nby = (h - 2 + rpw - 1) / rpw, nblocks = nbx * nby * batch;
+    dim3 grid(nblocks);
+#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap, nbx, nby, nblocks)
     switch (n_dog) {
         case 3: EXT(3); break; case 4: EXT(4); break; case 5: EXT(5); break;
         case 6: EXT(6); break; case 7: EXT(7); break; case 8: EXT(8); break;
