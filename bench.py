@@ -173,21 +173,22 @@ def main():
 
     if rank == 0:
         total_images = B * world * args.steps
-        # Dominant kernel: the Gaussian blur of octave 0 (6 launches per step: seed + 5 scales).
+        # Dominant kernel: the Gaussian blur with DoG epilogue on octave 0 (n_sca-1 = 5 launches per
+        # step; the seed launch, which evaluates the bilinear oversampling on the fly and writes no
+        # DoG, is a different instantiation and is timed separately).
         # Algorithmic bytes per octave-0 pixel and launch, fused kernel: read the source image (4 B),
-        # write the blurred image (4 B) and the DoG image (4 B) = 12 B.  The seed launch reads the
-        # input image instead (a quarter of the pixels when delta_min = 0.5: 1 B) and writes no DoG
-        # = 5 B; the launch that also emits the next octave's first image adds 1 B.
+        # write the blurred image (4 B) and the DoG image (4 B) = 12 B; the launch that also emits
+        # the next octave's first image adds 1 B (a quarter of the pixels).
         # Two-kernel form, row pass: read column-pass image and previous Gaussian image, write
-        # Gaussian and DoG image = 16 B (seed 8 B).
+        # Gaussian and DoG image = 16 B.
         n0 = ctx.dims[0][0] * ctx.dims[0][1]
         ms, launches = ctx.profile_read(dom, 0)
-        per_step = ctx.n_sca                       # seed + (n_sca-1) scales in octave 0
+        per_step = ctx.n_sca - 1
         if fused:
-            seed_read = 4.0 * (W_IM * H_IM) / n0          # input image bytes per octave-0 pixel
-            bytes_per_step = B * n0 * (seed_read + 4 + 12 * (ctx.n_sca - 1) + (1 if ctx.n_oct > 1 else 0))
-            kname = "k_blur_fused (column+row pass, DoG epilogue), octave 0"
+            bytes_per_step = B * n0 * (12 * (ctx.n_sca - 1) + (1 if ctx.n_oct > 1 else 0))
+            kname = "k_blur_fused<R,false> (column+row pass, DoG epilogue), octave 0, R = 5,7,8,10,13"
         else:
+            per_step = ctx.n_sca                     # the seed row pass is timed in the same class
             bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))
             kname = "k_blur_h (row pass + DoG epilogue), octave 0"
         steps_timed = launches / per_step if per_step else 0

@@ -447,7 +447,8 @@ static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, 
     a.w = c->L.w[o]; a.h = c->L.h[o]; a.batch = n;
     a.radius = b.radius; a.taps = b.taps; a.taps_dev = b.taps_dev;
     if (c->fused_blur && b.radius >= 1 && b.radius <= SA_MAX_RADIUS_FAST) {
-        ProfScope ps(c, st, SIFT_AMD_K_BLUR_FUSED, o);
+        // the seed launch that also evaluates the oversampling is timed as the oversampling class
+        ProfScope ps(c, st, ovs_w > 0 ? SIFT_AMD_K_OVERSAMPLE : SIFT_AMD_K_BLUR_FUSED, o);
         sa::launch_blur_fused(st, a);
         return;
     }

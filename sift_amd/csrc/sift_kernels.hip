@@ -20,6 +20,7 @@
 // Native 4-float vector: 16-byte LDS/global accesses compile to single b128 / dwordx4
 // instructions (HIP's float4 struct gets split into narrower accesses).
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f ld4(const float* p) { return *reinterpret_cast<const v4f*>(__builtin_assume_aligned(p, 16)); }
 __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d)
 {
@@ -380,8 +381,13 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 }
                 if (sub && !(row & 1) && (row >> 1) < ho) {
                     float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
-                    if ((xo >> 1) < wo) ps[0] = o4[0];
-                    if ((xo >> 1) + 1 < wo) ps[1] = o4[2];
+                    if (((wo & 1) == 0) && (xo >> 1) + 2 <= wo) {
+                        v2f v = {o4[0], o4[2]};
+                        *reinterpret_cast<v2f*>(__builtin_assume_aligned(ps, 8)) = v;
+                    } else {
+                        if ((xo >> 1) < wo) ps[0] = o4[0];
+                        if ((xo >> 1) + 1 < wo) ps[1] = o4[2];
+                    }
                 }
             }
         }
