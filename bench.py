@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--kind", default="smooth", choices=["smooth", "white"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--host-input", action="store_true",
+                    help="diagnostic: images start in pinned host memory and are copied to the GPU "
+                         "inside the timed region (PCIe-inclusive rate; not the headline value)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="contexts/streams used alternately (1 = strictly one batch at a time)")
     args = ap.parse_args()
@@ -121,6 +124,9 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(n_ctx)]
     ctx = ctxs[0]
 
+    h_pinned = torch.from_numpy(host).pin_memory() if args.host_input else None
+    d_stage = [torch.empty_like(d_imgs) for _ in range(n_ctx)] if args.host_input else None
+
     def run_steps(n_steps):
         """Queues n_steps batches; the gather of batch i is issued after batch i+1 is queued."""
         last = None
@@ -129,7 +135,12 @@ def main():
             k = i % n_ctx
             if len(pending) == n_ctx:
                 last = pending.pop(0).gather()
-            ctxs[k].detect_device(d_imgs.data_ptr(), B, streams[k].cuda_stream)
+            src = d_imgs
+            if args.host_input:
+                with torch.cuda.stream(streams[k]):
+                    d_stage[k].copy_(h_pinned, non_blocking=True)
+                src = d_stage[k]
+            ctxs[k].detect_device(src.data_ptr(), B, streams[k].cuda_stream)
             pending.append(ctxs[k])
         for c in pending:
             last = c.gather()
@@ -218,6 +229,8 @@ def main():
                 "octaves": ctx.n_oct,
                 "keypoints_per_image": float(nk.item()) / (B * world),
                 "sharding": "by image, no collective on the data path",
+                "input": "pinned host memory, H2D copy inside the timed region" if args.host_input
+                         else "resident in HBM",
             },
             "roofline": {
                 "bound": "hbm",

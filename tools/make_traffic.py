@@ -19,7 +19,9 @@ def per_launch(tag, name, counter, kernel_substr, grid_threads):
     path = glob.glob(f"{tag}/{name}/**/*counter_collection.csv", recursive=True)[0]
     per_dispatch = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
-        if kernel_substr in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) == grid_threads:
+        name = r["Kernel_Name"]
+        if kernel_substr in name and ", false," in name and r["Counter_Name"] == counter \
+                and int(r["Grid_Size"]) == grid_threads:
             per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
     vals = list(per_dispatch.values())
     return sum(vals) / len(vals), len(vals)
@@ -32,7 +34,7 @@ def main():
     fetch_kib, n1 = per_launch(tag, "fetch", "FETCH_SIZE", "k_blur_fused", grid)
     write_kib, n2 = per_launch(tag, "write", "WRITE_SIZE", "k_blur_fused", grid)
     rd, wr = 2.0 * fetch_kib * 1024, write_kib * 1024
-    rec = {"kernel": "k_blur_fused, octave 0 launches", "launches_sampled": [n1, n2],
+    rec = {"kernel": "k_blur_fused<R,false,...>, octave 0 launches (DoG-producing blurs)", "launches_sampled": [n1, n2],
            "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
            "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
            "bytes_per_launch": rd + wr,
