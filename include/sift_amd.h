@@ -145,6 +145,16 @@ struct sift_scalespace* sift_malloc_scalespace_dog_from_scalespace(struct sift_s
 struct sift_scalespace* sift_malloc_scalespace_lowe(int nOct, int nSca, int im_w, int im_h,
                                                     float delta_min, float sigma_min);
 
+/* lib_matching.h:49-65 (lib_matching.c:92-172): for every keypoint of k1 the two nearest
+ * descriptors of k2 (Euclidean); the pair is kept when the distance (flag 0) or the ratio of
+ * the two distances (flag 1) is below thresh.  Appends copies to the three output lists.
+ * k2 must hold at least two keypoints. */
+void matching(struct sift_keypoints* k1, struct sift_keypoints* k2, struct sift_keypoints* out_k1,
+              struct sift_keypoints* out_k2A, struct sift_keypoints* out_k2B, float thresh, int flag);
+void print_pairs(const struct sift_keypoints* k1, const struct sift_keypoints* k2);
+void save_pairs_extra(const char* name, const struct sift_keypoints* k1,
+                      const struct sift_keypoints* k2A, const struct sift_keypoints* k2B);
+
 /* ===================================================================== Part 2 == */
 /* No counterpart in the reference: batched, context-based interface.  Functions return 0
  * on success and a negative value on failure; sift_amd_last_error() describes the failure
@@ -202,6 +212,16 @@ int sift_amd_detect_device(sift_amd_ctx* ctx, const float* d_images, int n, void
 /* Same for host images: copies them to the device first. */
 int sift_amd_detect_host(sift_amd_ctx* ctx, const float* images, int n);
 
+/* 8-bit input: the conversion the reference's loader applies before sift_anatomy
+ * (io_png.c:480-520 gray = 0.2126 R + 0.7152 G + 0.0722 B evaluated in double and rounded to
+ * float, alpha dropped; sift_cli.c:280-281 division by 256) runs on the device, then the
+ * pipeline as above.  channels: 1 gray, 3 RGB, 4 RGBA, interleaved [n][h][w][channels]. */
+int sift_amd_detect_device_u8(sift_amd_ctx* ctx, const unsigned char* d_images, int n, int channels,
+                              void* stream);
+int sift_amd_detect_host_u8(sift_amd_ctx* ctx, const unsigned char* images, int n, int channels);
+/* The converted float images of the last *_u8 call ([n][h][w]), for inspection. */
+int sift_amd_copy_ingested(sift_amd_ctx* ctx, int n, float* dst);
+
 /* Scale-space only (oversample, blurs, DoG) on device-resident images. */
 int sift_amd_scalespace_device(sift_amd_ctx* ctx, const float* d_images, int n, void* stream);
 
@@ -235,6 +255,22 @@ int sift_amd_fetch_extras(sift_amd_ctx* ctx, int img, float* orihist, float* des
                           int max_keys);
 /* Smoothed orientation histograms of the list-F keypoints, in list order. */
 int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* ctx, int img, float* orihist, int max_n);
+/* Matching as lib_matching.c:92-135 on row-major host descriptors (n x dim, dim <= 256).
+ * For every query i of desc1: iA/iB = indices of its nearest and second nearest row of desc2,
+ * dA/dB their distances, pass[i] = 1 when the pair satisfies the threshold (flag as in
+ * `matching`).  All outputs have n1 entries; returns the number of passing queries, or a
+ * negative value.  The u8 form computes on the matrix cores and equals the float form on
+ * the same values. */
+int sift_amd_match_u8(int device, const unsigned char* desc1, int n1, const unsigned char* desc2,
+                      int n2, int dim, float thresh, int flag, int* iA, int* iB, float* dA,
+                      float* dB, unsigned char* pass);
+int sift_amd_match_f32(int device, const float* desc1, int n1, const float* desc2, int n2, int dim,
+                       float thresh, int flag, int* iA, int* iB, float* dA, float* dB,
+                       unsigned char* pass);
+/* Same between the keypoints of two images of the context's last run, without leaving the
+ * device; outputs need room for the keypoint count of img_a (cap entries given). */
+int sift_amd_match_images(sift_amd_ctx* ctx, int img_a, int img_b, float thresh, int flag, int* iA,
+                          int* iB, float* dA, float* dB, unsigned char* pass, int cap);
 /* Frees the context that the reference-named entry points keep per host thread. */
 void sift_amd_release_thread_cache(void);
 

@@ -70,6 +70,12 @@ def lib():
         L.os_number_of_octaves.argtypes = [C.c_int, C.c_int, C.POINTER(abi.SiftParameters)]
         L.os_convert_threshold.restype = C.c_float
         L.os_convert_threshold.argtypes = [C.POINTER(abi.SiftParameters)]
+        L.os_matching.restype = C.c_int
+        L.os_matching.argtypes = [abi.c_float_p, C.c_int, abi.c_float_p, C.c_int, C.c_int, C.c_float,
+                                  C.c_int, abi.c_int_p, abi.c_int_p, abi.c_float_p, abi.c_float_p,
+                                  C.POINTER(C.c_ubyte)]
+        L.os_ingest_u8.restype = None
+        L.os_ingest_u8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, abi.c_float_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -141,3 +147,30 @@ def gradient(im):
     lib().os_gradient(im.ctypes.data_as(abi.c_float_p), gi.ctypes.data_as(abi.c_float_p),
                       gj.ctypes.data_as(abi.c_float_p), w, h)
     return gi, gj
+
+
+def matching(d1, d2, thresh=0.6, flag=1):
+    """-> dict iA, iB, dA, dB, pass for every row of d1 (float descriptors n x dim)."""
+    d1 = np.ascontiguousarray(d1, np.float32)
+    d2 = np.ascontiguousarray(d2, np.float32)
+    n1, dim = d1.shape
+    n2 = d2.shape[0]
+    assert n2 >= 2 and d2.shape[1] == dim
+    iA, iB = np.zeros(n1, np.int32), np.zeros(n1, np.int32)
+    dA, dB = np.zeros(n1, np.float32), np.zeros(n1, np.float32)
+    ok = np.zeros(n1, np.uint8)
+    lib().os_matching(d1.ctypes.data_as(abi.c_float_p), n1, d2.ctypes.data_as(abi.c_float_p), n2, dim,
+                      C.c_float(thresh), flag, iA.ctypes.data_as(abi.c_int_p),
+                      iB.ctypes.data_as(abi.c_int_p), dA.ctypes.data_as(abi.c_float_p),
+                      dB.ctypes.data_as(abi.c_float_p), ok.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return {"iA": iA, "iB": iB, "dA": dA, "dB": dB, "pass": ok}
+
+
+def ingest_u8(a):
+    """u8 (h,w) or (h,w,3|4) -> float32 (h,w) as the reference's loader + sift_cli produce it."""
+    a = np.ascontiguousarray(a, np.uint8)
+    ch = 1 if a.ndim == 2 else a.shape[2]
+    out = np.empty(a.shape[:2], np.float32)
+    lib().os_ingest_u8(a.ctypes.data_as(C.POINTER(C.c_ubyte)), ch, out.ctypes.data_as(abi.c_float_p),
+                       out.size)
+    return out

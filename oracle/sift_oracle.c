@@ -681,6 +681,61 @@ os_result *os_sift(const float *x, int w, int h, const os_params *p, int flags)
     return r;
 }
 
+/* ------------------------------------------------------------------ matching --
+ * [lib_matching.c:57-135] with [lib_util.c:108-153].  d1: n1 x dim, d2: n2 x dim (n2 >= 2).
+ * For each row of d1: indices and distances of its two nearest rows of d2 and whether the
+ * pair passes (flag 1: dA/dB < thresh, flag 0: dA < thresh).  Returns the number passing. */
+int os_matching(const float *d1, int n1, const float *d2, int n2, int dim, float thresh, int flag,
+                int *iA, int *iB, float *dA, float *dB, unsigned char *pass)
+{
+    int count = 0;
+    float *dist = (float *)malloc((size_t)(n2 > 0 ? n2 : 1) * sizeof(float));
+    for (int i = 0; i < n1; i++) {
+        for (int j = 0; j < n2; j++) {                 /* [lib_util.c:137-153] */
+            float d = 0.0f;
+            for (int k = 0; k < dim; k++) {
+                float t = d1[(size_t)i * dim + k] - d2[(size_t)j * dim + k];
+                d += t * t;
+            }
+            dist[j] = (float)sqrt(d);
+        }
+        int a, b;                                      /* [lib_util.c:108-134] */
+        float ma, mb;
+        if (dist[0] < dist[1]) { a = 0; b = 1; ma = dist[0]; mb = dist[1]; }
+        else                   { a = 1; b = 0; ma = dist[1]; mb = dist[0]; }
+        for (int j = 2; j < n2; j++) {
+            if (dist[j] < ma)      { mb = ma; ma = dist[j]; b = a; a = j; }
+            else if (dist[j] < mb) { mb = dist[j]; b = j; }
+        }
+        iA[i] = a; iB[i] = b; dA[i] = ma; dB[i] = mb;
+        float val = (flag == 1 ? ma / mb : ma);        /* [lib_matching.c:115] */
+        pass[i] = (unsigned char)(val < thresh);
+        count += pass[i];
+    }
+    free(dist);
+    return count;
+}
+
+/* -------------------------------------------------------------------- ingest --
+ * 8-bit interleaved pixels -> the float image handed to sift_anatomy by the command-line
+ * tool: [io_png.c:491-520] (gray kept, RGB weighted in double, alpha dropped by
+ * PNG_TRANSFORM_STRIP_ALPHA at :486-487) then [sift_cli.c:280-281]. */
+void os_ingest_u8(const unsigned char *in, int channels, float *out, size_t n_px)
+{
+    for (size_t p = 0; p < n_px; p++) {
+        float g;
+        if (channels == 1) {
+            g = (float)in[p];
+        } else {
+            float r = (float)in[p * channels], gg = (float)in[p * channels + 1], b = (float)in[p * channels + 2];
+            g = (float)(0.212639005871510 * r + 0.715168678767756 * gg + 0.072192315360734 * b);
+        }
+        g /= 256.0;
+        out[p] = g;
+    }
+}
+
+
 void os_free(os_result *r)
 {
     if (!r) return;

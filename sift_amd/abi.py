@@ -131,7 +131,23 @@ def bind_reference_api(lib):
     lib.sift_fill_descriptors.argtypes = [c_float_p, C.c_int, C.c_int, P(SiftKeypointStd), C.c_int]
     lib.sift_find_ori_and_fill_descriptors.restype = None
     lib.sift_find_ori_and_fill_descriptors.argtypes = lib.sift_fill_descriptors.argtypes
+    if hasattr(lib, "matching"):
+        lib.matching.restype = None
+        lib.matching.argtypes = [P(SiftKeypoints)] * 5 + [C.c_float, C.c_int]
     return lib
+
+
+def keypoints_from_numpy(lib, descr, n_hist=4, n_ori=8, n_bins=36, xy=None):
+    """Build a malloc'd struct sift_keypoints list holding the given float descriptors
+    (n x n_hist*n_hist*n_ori); x,y default to (row index, 0).  Free with sift_free_keypoints."""
+    descr = np.ascontiguousarray(descr, np.float32)
+    lst = lib.sift_malloc_keypoints()
+    for i in range(len(descr)):
+        k = lib.sift_malloc_keypoint(n_ori, n_hist, n_bins)
+        C.memmove(k.contents.descr, descr[i].ctypes.data, descr.shape[1] * 4)
+        k.contents.x, k.contents.y = (float(i), 0.0) if xy is None else (float(xy[i][0]), float(xy[i][1]))
+        lib.sift_add_keypoint_to_list(k, lst)
+    return lst
 
 
 def scalespace_to_numpy(ss_ptr):

@@ -78,6 +78,13 @@ def lib():
     L.sift_amd_fetch_stage_f_histograms.argtypes = [vp, C.c_int, vp, C.c_int]
     L.sift_amd_profile_enable.argtypes = [vp, C.c_uint]
     L.sift_amd_profile_read.argtypes = [vp, C.c_int, C.c_int, P(C.c_double), P(C.c_longlong), C.c_int]
+    L.sift_amd_detect_device_u8.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.sift_amd_detect_host_u8.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.sift_amd_copy_ingested.argtypes = [vp, C.c_int, abi.c_float_p]
+    match_out = [abi.c_int_p, abi.c_int_p, abi.c_float_p, abi.c_float_p, P(C.c_ubyte)]
+    L.sift_amd_match_u8.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out
+    L.sift_amd_match_f32.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out
+    L.sift_amd_match_images.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out + [C.c_int]
     L.sift_amd_release_thread_cache.restype = None
     _lib = L
     return L
@@ -147,6 +154,38 @@ class Context:
         if self.L.sift_amd_detect_host(self.ptr, images.ctypes.data_as(abi.c_float_p), n):
             raise _err("sift_amd_detect_host")
         self.last_n = n
+
+    def detect_device_u8(self, d_ptr, n, channels, stream=None):
+        if self.L.sift_amd_detect_device_u8(self.ptr, d_ptr, n, channels, stream):
+            raise _err("sift_amd_detect_device_u8")
+        self.last_n = n
+
+    def detect_host_u8(self, images):
+        """images: uint8 (n,h,w) gray or (n,h,w,3|4) interleaved colour."""
+        images = np.ascontiguousarray(images, np.uint8)
+        ch = 1 if images.ndim == 3 else images.shape[3]
+        n, h, w = images.shape[:3]
+        if (w, h) != (self.w, self.h):
+            raise ValueError(f"image size {w}x{h} does not match the context ({self.w}x{self.h})")
+        if self.L.sift_amd_detect_host_u8(self.ptr, images.ctypes.data, n, ch):
+            raise _err("sift_amd_detect_host_u8")
+        self.last_n = n
+
+    def ingested(self, n=None):
+        n = self.last_n if n is None else n
+        out = np.empty((n, self.h, self.w), np.float32)
+        if self.L.sift_amd_copy_ingested(self.ptr, n, out.ctypes.data_as(abi.c_float_p)):
+            raise _err("sift_amd_copy_ingested")
+        return out
+
+    def match(self, img_a, img_b, thresh=0.6, flag=1):
+        """Two nearest neighbours in image b of every keypoint of image a (last run)."""
+        n = int(self.counts()[img_a])
+        out = _match_buffers(n)
+        m = self.L.sift_amd_match_images(self.ptr, img_a, img_b, thresh, flag, *_match_args(out), max(n, 1))
+        if m < 0:
+            raise _err("sift_amd_match_images")
+        return out
 
     # ---- results
     def counts(self):
@@ -242,6 +281,34 @@ class Context:
     # ---- sizes of the work (for roofline accounting)
     def pixels_per_octave(self):
         return [w * h for (w, h) in self.dims]
+
+
+def _match_buffers(n):
+    return {"iA": np.zeros(n, np.int32), "iB": np.zeros(n, np.int32), "dA": np.zeros(n, np.float32),
+            "dB": np.zeros(n, np.float32), "pass": np.zeros(n, np.uint8)}
+
+
+def _match_args(o):
+    return (o["iA"].ctypes.data_as(abi.c_int_p), o["iB"].ctypes.data_as(abi.c_int_p),
+            o["dA"].ctypes.data_as(abi.c_float_p), o["dB"].ctypes.data_as(abi.c_float_p),
+            o["pass"].ctypes.data_as(C.POINTER(C.c_ubyte)))
+
+
+def match(desc1, desc2, thresh=0.6, flag=1, device=0):
+    """lib_matching.c:92-135 on the GPU.  uint8 descriptors use the integer (matrix-core) path,
+    anything else the float path.  Returns per-query iA, iB, dA, dB, pass."""
+    a, b = np.asarray(desc1), np.asarray(desc2)
+    u8 = a.dtype == np.uint8 and b.dtype == np.uint8
+    a = np.ascontiguousarray(a, np.uint8 if u8 else np.float32)
+    b = np.ascontiguousarray(b, np.uint8 if u8 else np.float32)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("descriptors must be (n1, dim) and (n2, dim)")
+    out = _match_buffers(len(a))
+    fn = lib().sift_amd_match_u8 if u8 else lib().sift_amd_match_f32
+    m = fn(device, a.ctypes.data, len(a), b.ctypes.data, len(b), a.shape[1], thresh, flag, *_match_args(out))
+    if m < 0:
+        raise _err("sift_amd_match")
+    return out
 
 
 def sift_compute_features(img):

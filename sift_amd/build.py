@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsift_amd.so")
-SOURCES = ["sift_kernels.hip", "sift_ctx.hip", "sift_compat.hip"]
+SOURCES = ["sift_kernels.hip", "sift_ctx.hip", "sift_compat.hip", "sift_match.hip"]
 # -ffp-contract=off is part of the numerical contract: the blur/DoG/refinement arithmetic must
 # not be fused into FMAs (see the header of sift_kernels.hip).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",

@@ -31,4 +31,6 @@ int sa_ctx_limits(const sift_amd_ctx* c, int* cap, int* fcap, int* kcap);
 const SaLayout* sa_ctx_layout(const sift_amd_ctx* c);
 const sift_parameters* sa_ctx_params(const sift_amd_ctx* c);
 float* sa_ctx_input_buffer(sift_amd_ctx* c);
+// device records of the final keypoints of one image of the last run (waits for it)
+int sa_ctx_image_keys(sift_amd_ctx* c, int img, const void** d_std, const float** d_descr, int* n, int* n_descr);
 hipStream_t sa_ctx_stream(sift_amd_ctx* c);

@@ -140,6 +140,8 @@ struct sift_amd_ctx {
     int last_n = 0;
 
     float *d_in = nullptr, *d_seed = nullptr, *d_tmp = nullptr;
+    unsigned char* d_u8 = nullptr;      // staging of 8-bit host images, grown on demand
+    size_t d_u8_bytes = 0;
     float* d_gss[SA_MAX_OCT] = {};
     float* d_dog[SA_MAX_OCT] = {};
     int cap = 0, fcap = 0, kcap = 0;
@@ -358,6 +360,7 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
     }
     if (c->capture_stream) hipStreamDestroy(c->capture_stream);
     for (void* v : c->allocs) hipFree(v);
+    if (c->d_u8) hipFree(c->d_u8);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -634,6 +637,57 @@ extern "C" int sift_amd_detect_host(sift_amd_ctx* c, const float* images, int n)
     HIP_TRY(hipMemcpyAsync(c->d_in, images, (size_t)n * c->im_w * c->im_h * sizeof(float),
                            hipMemcpyHostToDevice, c->own_stream));
     return sift_amd_detect_device(c, c->d_in, n, nullptr);
+}
+
+// 8-bit input: convert into the context's float input buffer on the run's stream, then run.
+// The device pointer must be 4-byte aligned (hipMalloc'd buffers are).
+extern "C" int sift_amd_detect_device_u8(sift_amd_ctx* c, const unsigned char* d_images, int n, int channels,
+                                         void* stream)
+{
+    if (channels != 1 && channels != 3 && channels != 4) { sa_set_error("channels must be 1, 3 or 4 (got %d)", channels); return -1; }
+    if (((uintptr_t)d_images & 3) != 0) { sa_set_error("8-bit device images must be 4-byte aligned"); return -1; }
+    hipStream_t st = pick_stream(c, stream);
+    if (begin_run(c, n, st)) return -1;
+    sa::launch_ingest_u8(st, d_images, channels, c->d_in, (long long)n * c->im_w * c->im_h);
+    HIP_TRY(hipGetLastError());
+    return run_graphed(c, c->d_in, n, st, 1);
+}
+
+extern "C" int sift_amd_detect_host_u8(sift_amd_ctx* c, const unsigned char* images, int n, int channels)
+{
+    if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
+    if (channels != 1 && channels != 3 && channels != 4) { sa_set_error("channels must be 1, 3 or 4 (got %d)", channels); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * c->im_w * c->im_h * channels;
+    if (bytes > c->d_u8_bytes) {
+        if (c->d_u8) HIP_TRY(hipFree(c->d_u8));
+        c->d_u8 = nullptr; c->d_u8_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_u8, bytes));
+        c->d_u8_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_u8, images, bytes, hipMemcpyHostToDevice, c->own_stream));
+    return sift_amd_detect_device_u8(c, c->d_u8, n, channels, nullptr);
+}
+
+extern "C" int sift_amd_copy_ingested(sift_amd_ctx* c, int n, float* dst)
+{
+    if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(dst, c->d_in, (size_t)n * c->im_w * c->im_h * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sa_ctx_image_keys(sift_amd_ctx* c, int img, const void** d_std, const float** d_descr, int* n, int* n_descr)
+{
+    if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
+    if (sa_sync_counters(c)) return -1;
+    *n = c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS];
+    *d_std = c->d_std + (size_t)img * c->kcap;
+    *d_descr = c->d_descr + (size_t)img * c->kcap * SA_MAX_DESCR;
+    *n_descr = c->p.n_hist * c->p.n_hist * c->p.n_ori;
+    return 0;
 }
 
 int sa_sync_counters(sift_amd_ctx* c)

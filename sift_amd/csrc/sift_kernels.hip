@@ -101,6 +101,42 @@ k_oversample(const float* __restrict__ in, int wi, int hi, long long s_in,
         __fadd_rn(__fmul_rn(fx, top), __fmul_rn(1 - fx, bot));
 }
 
+// 8-bit pixels -> float gray / 256: io_png.c:480-520 (BT.709 weights applied in double on
+// the float channel values, rounded to float once) followed by sift_cli.c:280-281.  Four
+// pixels per thread.
+template <int CH>
+__global__ void __launch_bounds__(256)
+k_ingest_u8(const unsigned char* __restrict__ in, float* __restrict__ out, long long n_px)
+{
+    const long long p0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= n_px) return;
+    unsigned char b[4 * CH];
+    if (p0 + 4 <= n_px) {
+        const unsigned* w = reinterpret_cast<const unsigned*>(in + p0 * CH);   // 4*CH bytes, 4-byte aligned
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            const unsigned v = w[k];
+            b[4 * k] = v & 0xff; b[4 * k + 1] = (v >> 8) & 0xff; b[4 * k + 2] = (v >> 16) & 0xff; b[4 * k + 3] = v >> 24;
+        }
+    } else {
+        for (int k = 0; k < 4 * CH; k++) b[k] = p0 * CH + k < n_px * CH ? in[p0 * CH + k] : 0;
+    }
+    float g[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (CH == 1) {
+            g[e] = (float)b[e];
+        } else {
+            const double r = (double)(float)b[e * CH], gg = (double)(float)b[e * CH + 1], bl = (double)(float)b[e * CH + 2];
+            g[e] = (float)__dadd_rn(__dadd_rn(__dmul_rn(0.212639005871510, r), __dmul_rn(0.715168678767756, gg)),
+                                    __dmul_rn(0.072192315360734, bl));
+        }
+        g[e] = (float)((double)g[e] / 256.0);
+    }
+    if (p0 + 4 <= n_px) st4(out + p0, g[0], g[1], g[2], g[3]);
+    else for (int e = 0; p0 + e < n_px; e++) out[p0 + e] = g[e];
+}
+
 // lib_discrete.c:180-191
 __global__ void __launch_bounds__(256)
 k_subsample2(const float* __restrict__ in, int wi, long long s_in,
@@ -1429,6 +1465,14 @@ void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long lon
 {
     dim3 grid((wo + 255) / 256, ho, batch);
     HIPK(k_oversample, grid, dim3(256), 0, st, in, wi, hi, s_in, out, wo, ho, s_out, delta);
+}
+
+void launch_ingest_u8(hipStream_t st, const unsigned char* in, int channels, float* out, long long n_px)
+{
+    const dim3 grid((unsigned)((n_px + 1023) / 1024)), block(256);
+    if (channels == 1) hipLaunchKernelGGL(k_ingest_u8<1>, grid, block, 0, st, in, out, n_px);
+    else if (channels == 3) hipLaunchKernelGGL(k_ingest_u8<3>, grid, block, 0, st, in, out, n_px);
+    else hipLaunchKernelGGL(k_ingest_u8<4>, grid, block, 0, st, in, out, n_px);
 }
 
 void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,

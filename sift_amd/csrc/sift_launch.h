@@ -29,6 +29,7 @@ void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
 bool launch_blur_fused(hipStream_t st, const BlurArgs& a);
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
                        float* out, int wo, int ho, long long s_out, float delta, int batch);
+void launch_ingest_u8(hipStream_t st, const unsigned char* in, int channels, float* out, long long n_px);
 void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,
                       float* out, int wo, int ho, long long s_out, int batch);
 void launch_sub(hipStream_t st, const float* a, const float* b, float* out, long long n,
