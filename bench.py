@@ -189,14 +189,15 @@ def main():
         # DoG, is a different instantiation and is timed separately).
         # Algorithmic bytes per octave-0 pixel and launch, fused kernel: read the source image (4 B),
         # write the blurred image (4 B) and the DoG image (4 B) = 12 B; the launch that also emits
-        # the next octave's first image adds 1 B (a quarter of the pixels).
+        # the next octave's first image adds 1 B (a quarter of the pixels); the last launch does not
+        # store its blurred image (only its DoG is used), 4 B less.
         # Two-kernel form, row pass: read column-pass image and previous Gaussian image, write
         # Gaussian and DoG image = 16 B.
         n0 = ctx.dims[0][0] * ctx.dims[0][1]
         ms, launches = ctx.profile_read(dom, 0)
         per_step = ctx.n_sca - 1
         if fused:
-            bytes_per_step = B * n0 * (12 * (ctx.n_sca - 1) + (1 if ctx.n_oct > 1 else 0))
+            bytes_per_step = B * n0 * (12 * (ctx.n_sca - 1) - 4 + (1 if ctx.n_oct > 1 else 0))
             kname = "k_blur_fused<R,false> (column+row pass, DoG epilogue), octave 0, R = 5,7,8,10,13"
         else:
             per_step = ctx.n_sca                     # the seed row pass is timed in the same class

@@ -166,8 +166,11 @@ typedef struct sift_amd_ctx sift_amd_ctx;
 #define SIFT_AMD_MAX_SCA 12
 
 enum {
-    SIFT_AMD_KEEP_ALL_EXTREMA = 1  /* list every discrete extremum (needed to reproduce kk[0]);
+    SIFT_AMD_KEEP_ALL_EXTREMA = 1, /* list every discrete extremum (needed to reproduce kk[0]);
                                       default keeps only those passing the first contrast test */
+    SIFT_AMD_KEEP_SCALESPACE = 2   /* store every Gaussian image; by default the last one of each
+                                      octave, which only its DoG needs, is never written
+                                      (required by sift_amd_copy_scalespace(which = 0)) */
 };
 
 /* Kernel classes for the built-in event timers. */
@@ -238,7 +241,10 @@ int sift_amd_fetch_keypoints(sift_amd_ctx* ctx, int img, struct sift_keypoint_st
 int sift_amd_gather_keypoints(sift_amd_ctx* ctx, struct sift_keypoint_std** out, int* counts);
 
 /* Stage-level access for parity tooling.  stage_sizes[0..5] are the sizes of the lists
- * A..F of lib_sift_anatomy.c:843-848, extrema_per_octave the discrete-extrema counts. */
+ * A..F of lib_sift_anatomy.c:843-848, extrema_per_octave the discrete-extrema counts.
+ * Without SIFT_AMD_KEEP_ALL_EXTREMA the scan skips regions in which no sample passes the
+ * first contrast test, so extrema below that threshold are not counted: stage_sizes[0] and
+ * the per-octave counts are then reported as -1 (lists B..F are unaffected). */
 int sift_amd_stage_counts(sift_amd_ctx* ctx, int img, int stage_sizes[6],
                           int extrema_per_octave[SIFT_AMD_MAX_OCT]);
 /* Candidate records in canonical (o,s,i,j)-of-seed order with the last stage each reached

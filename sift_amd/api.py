@@ -22,6 +22,7 @@ K_OVERSAMPLE, K_SUBSAMPLE, K_BLUR_V, K_BLUR_H, K_EXTREMA, K_REFINE, K_RANK, K_OR
 KERNEL_CLASSES = ["oversample", "subsample", "blur_v", "blur_h", "extrema", "refine", "rank",
                   "orientation", "expand", "descriptor", "blur_fused"]
 KEEP_ALL_EXTREMA = 1
+KEEP_SCALESPACE = 2
 
 
 class Geometry(C.Structure):
@@ -101,11 +102,12 @@ def device_count():
 class Context:
     """Pyramid pool + pipeline for up to `max_batch` images of w x h on one GPU."""
 
-    def __init__(self, w, h, max_batch=1, params=None, device=0, keep_all_extrema=False):
+    def __init__(self, w, h, max_batch=1, params=None, device=0, keep_all_extrema=False,
+                 keep_scalespace=False):
         self.L = lib()
         self.w, self.h, self.max_batch = w, h, max_batch
         self.params = params if params is not None else abi.SiftParameters.default()
-        flags = KEEP_ALL_EXTREMA if keep_all_extrema else 0
+        flags = (KEEP_ALL_EXTREMA if keep_all_extrema else 0) | (KEEP_SCALESPACE if keep_scalespace else 0)
         self.ptr = self.L.sift_amd_create(device, w, h, max_batch, C.byref(self.params), flags)
         if not self.ptr:
             raise _err("sift_amd_create")

@@ -256,7 +256,7 @@ static struct sift_keypoints* run_full(const float* x, int w, int h, const sift_
                                        struct sift_scalespace** ss, int n_ss, struct sift_keypoints** kk,
                                        int n_lists, bool describe)
 {
-    sift_amd_ctx* c = get_ctx(w, h, p, SIFT_AMD_KEEP_ALL_EXTREMA);
+    sift_amd_ctx* c = get_ctx(w, h, p, SIFT_AMD_KEEP_ALL_EXTREMA | SIFT_AMD_KEEP_SCALESPACE);
     hipStream_t st = sa_ctx_stream(c);
     if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
         sa_set_error("input upload failed");
@@ -435,7 +435,7 @@ extern "C" void scalespace_compute(struct sift_scalespace* ss, const float* imag
     sift_parameters p;
     sa_default_parameters(&p);
     p.n_spo = L.n_sca - 3; p.delta_min = L.delta[0]; p.sigma_min = L.sigmas[0][0]; p.sigma_in = sigma_in;
-    sift_amd_ctx* c = sa_create_from_layout(env_device(), im_w, im_h, 1, &p, &L, sigma_in, 0);
+    sift_amd_ctx* c = sa_create_from_layout(env_device(), im_w, im_h, 1, &p, &L, sigma_in, SIFT_AMD_KEEP_SCALESPACE);
     if (!c) die("scalespace_compute");
     if (hipMemcpy(sa_ctx_input_buffer(c), image, (size_t)im_w * im_h * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         sa_set_error("input upload failed");

@@ -140,6 +140,11 @@ struct sift_amd_ctx {
     int last_n = 0;
 
     float *d_in = nullptr, *d_seed = nullptr, *d_tmp = nullptr;
+    // marks of the 8-row x 64-column DoG cells that hold a sample passing the first contrast
+    // test, per octave [batch][ceil(h/8)][ceil(w/64)], one allocation (d_cells[0] is its start)
+    int* d_cells[SA_MAX_OCT] = {};
+    size_t cells_total = 0;             // ints
+    bool cells_valid[SA_MAX_OCT] = {};  // set by the scale-space run when every centre-scale blur marked
     unsigned char* d_u8 = nullptr;      // staging of 8-bit host images, grown on demand
     size_t d_u8_bytes = 0;
     float* d_gss[SA_MAX_OCT] = {};
@@ -168,6 +173,7 @@ struct sift_amd_ctx {
         hipGraphExec_t exec; std::vector<ProfEvent> events;
     };
     bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
+    bool use_cells = true;          // SIFT_AMD_CELLS=0: the extrema scan visits every sample
     std::vector<GraphEntry*> graphs;
     GraphEntry* capturing = nullptr;
     hipStream_t capture_stream = nullptr;
@@ -248,6 +254,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
     if (const char* m = getenv("SIFT_AMD_BLUR")) c->fused_blur = strcmp(m, "split") != 0;
     if (const char* m = getenv("SIFT_AMD_GRAPH")) c->use_graph = atoi(m) != 0;
+    if (const char* m = getenv("SIFT_AMD_CELLS")) c->use_cells = atoi(m) != 0;
 
     for (int o = 1; o < L->n_oct; o++)
         if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
@@ -313,6 +320,15 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     if (dev_alloc(c, &c->d_ref, (size_t)(B * c->cap))) return fail();
     if (dev_alloc(c, &c->d_stage, (size_t)(B * c->cap))) return fail();
     if (dev_alloc(c, &c->d_counters, (size_t)(B * SA_CNT_STRIDE))) return fail();
+    {
+        size_t off[SA_MAX_OCT + 1] = {0};
+        for (int o = 0; o < L->n_oct; o++)
+            off[o + 1] = off[o] + (size_t)B * ((L->h[o] + 7) / 8) * ((L->w[o] + 63) / 64);
+        c->cells_total = off[L->n_oct];
+        int* cells = nullptr;
+        if (dev_alloc(c, &cells, c->cells_total)) return fail();
+        for (int o = 0; o < L->n_oct; o++) c->d_cells[o] = cells + off[o];
+    }
     if (dev_alloc(c, &c->d_flist, (size_t)(B * c->fcap))) return fail();
     if (dev_alloc(c, &c->d_given, (size_t)(B * c->fcap))) return fail();
     if (dev_alloc(c, &c->d_ori_n, (size_t)(B * c->fcap))) return fail();
@@ -441,9 +457,11 @@ extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, doubl
 
 static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
                      float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n,
-                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f)
+                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, bool skip_out = false, int* cells = nullptr)
 {
     sa::BlurArgs a;
+    a.skip_out = skip_out;
+    a.flags = cells; a.flag_thr = c->sc.thr_pre;
     a.ovs_w = ovs_w; a.ovs_h = ovs_h; a.ovs_delta = ovs_delta;
     a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog; a.sub = sub;
     a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog; a.s_sub = s_sub;
@@ -467,7 +485,12 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
 {
     const SaLayout& L = c->L;
     const int ns = L.n_sca;
+    // Cell marks let the extrema scan skip regions without any contrast-passing sample.  They
+    // are of no use when every discrete extremum has to be listed.
+    const bool mark = !(c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) && c->fused_blur && c->use_cells;
+    if (mark) HIP_TRY(hipMemsetAsync(c->d_cells[0], 0, c->cells_total * sizeof(int), st));
     for (int o = 0; o < L.n_oct; o++) {
+        c->cells_valid[o] = mark;
         const long long np = (long long)L.w[o] * L.h[o];
         const long long sg = ns * np, sd = (ns - 1) * np;
         float* g = c->d_gss[o];
@@ -496,7 +519,17 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 sub = c->d_gss[o + 1];
                 s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
             }
-            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, sub, s_sub, n);
+            // the last Gaussian image is read by nothing but its own DoG (keypoints live on scales
+            // 1..n_spo): it is stored only for callers that download the scale-space
+            const bool skip = s == ns - 1 && !(c->flags & SIFT_AMD_KEEP_SCALESPACE);
+            // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
+            int* cells = nullptr;
+            if (mark && s - 1 >= 1 && s - 1 <= ns - 3) {
+                if (c->step[o][s].radius >= 1 && c->step[o][s].radius <= SA_MAX_RADIUS_FAST) cells = c->d_cells[o];
+                else c->cells_valid[o] = false;
+            }
+            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, sub, s_sub, n,
+                     0, 0, 0.f, skip, cells);
         }
     }
     hipError_t e = hipGetLastError();
@@ -513,7 +546,8 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
         const long long np = (long long)L.w[o] * L.h[o];
         ProfScope ps(c, st, SIFT_AMD_K_EXTREMA, o);
         if (sa::launch_extrema(st, c->d_dog[o], (L.n_sca - 1) * np, L.w[o], L.h[o], L.n_sca - 1, o,
-                               c->sc.thr_pre, emit_all, c->d_ckey, c->d_cval, c->d_counters, c->cap, n)) {
+                               c->sc.thr_pre, emit_all, c->d_ckey, c->d_cval, c->d_counters, c->cap, n,
+                               c->cells_valid[o] && !emit_all ? c->d_cells[o] : nullptr)) {
             sa_set_error("unsupported number of DoG images %d", L.n_sca - 1);
             return -1;
         }
@@ -760,6 +794,10 @@ extern "C" int sift_amd_stage_counts(sift_amd_ctx* c, int img, int stage_sizes[6
     const int* cnt = c->h_counters + img * SA_CNT_STRIDE;
     for (int k = 0; k < 6; k++) stage_sizes[k] = cnt[SA_CNT_STAGE + k];
     for (int o = 0; o < SA_MAX_OCT; o++) ext_oct[o] = cnt[SA_CNT_EXT_OCT + o];
+    // where the scan skipped cells without a contrast-passing sample, extrema below the
+    // contrast threshold were not counted
+    for (int o = 0; o < c->L.n_oct; o++)
+        if (c->cells_valid[o]) { stage_sizes[0] = -1; ext_oct[o] = -1; }
     return 0;
 }
 
@@ -805,6 +843,10 @@ extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int
 {
     if (img < 0 || img >= c->batch || o < 0 || o >= c->L.n_oct || which < 0 || which > 1) {
         sa_set_error("bad image/octave/which");
+        return -1;
+    }
+    if (which == 0 && !(c->flags & SIFT_AMD_KEEP_SCALESPACE)) {
+        sa_set_error("the Gaussian stack is only complete in a context created with SIFT_AMD_KEEP_SCALESPACE");
         return -1;
     }
     HIP_TRY(hipSetDevice(c->device));

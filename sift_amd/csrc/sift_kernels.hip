@@ -283,8 +283,12 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
 // Per pixel the kernel reads the source image once (plus the strip/tile halo, served by L2)
 // and writes gss[s] and dog[s-1]; the column-pass image never exists in memory.  Operation
 // order per output is identical to the two-kernel form, so results are bit-identical.
+// `flags`, if given, gets a mark per 8-row x 64-column cell of the image in which some DoG
+// sample exceeds flag_thr in magnitude (cells [image][row/8][col/64]); the extrema scan skips
+// unmarked cells.
 // `sub`, if given, receives the even samples (the next octave's first image,
-// lib_discrete.c:180-191).
+// lib_discrete.c:180-191).  `out` may be null: the last Gaussian image of an octave is only
+// needed for its DoG, so the fast path does not store it.
 // Source sample (i, col) of the fused blur when the source is the bilinearly oversampled
 // input (OVS): same expression and operation order as k_oversample / lib_discrete.c:207-237.
 struct OvsCol { int jm, jp; float fy; };
@@ -310,7 +314,7 @@ __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
              long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks,
-             int wi, int hi, float delta)
+             int wi, int hi, float delta, int* __restrict__ flags, float flag_thr)
 {
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
     // the row pass free of bank conflicts also where a wave straddles two rows.
@@ -394,13 +398,15 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 }
                 const bool vec = vec_w && (xo + 4 <= w);
                 const long long off = (long long)row * w + xo;
-                float* po = out + b * s_out + off;
-                if (vec) {
-                    st4(po, o4[0], o4[1], o4[2], o4[3]);
-                } else {
+                if (out) {
+                    float* po = out + b * s_out + off;
+                    if (vec) {
+                        st4(po, o4[0], o4[1], o4[2], o4[3]);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (xo + q < w) po[q] = o4[q];
+                        for (int q = 0; q < 4; ++q)
+                            if (xo + q < w) po[q] = o4[q];
+                    }
                 }
                 if (dog) {
                     const v4f pv = ld4(&l_prev[buf][hg][RP + 4 * hq]);
@@ -413,6 +419,13 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             if (xo + q < w) pd[q] = d4[q];
+                    }
+                    // mark the 8-row x 64-column cell if a sample passes the first contrast test
+                    // (columns past w hold mirrored data and only ever add marks)
+                    if (flags) {
+                        const float m = fmaxf(fmaxf(fabsf(d4[0]), fabsf(d4[1])), fmaxf(fabsf(d4[2]), fabsf(d4[3])));
+                        if (m > flag_thr)
+                            flags[(b * ((h + 7) >> 3) + (row >> 3)) * (long long)((w + 63) >> 6) + (xo >> 6)] = 1;
                     }
                 }
                 if (sub && !(row & 1) && (row >> 1) < ho) {
@@ -585,33 +598,14 @@ __device__ __forceinline__ void ext_eval(const ExtWin<NDOG>& W, bool lane_ok, in
     }
 }
 
+// Walks output rows [ibeg, iend) of one wave's column segment.
 template <int NDOG>
-__global__ void __launch_bounds__(256)
-k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
-          float thr_pre, int emit_all, int rows_per_wave,
-          unsigned long long* __restrict__ ckey, float* __restrict__ cval,
-          int* __restrict__ counters, int cap, int nbx, int nby, int nblocks)
+__device__ __forceinline__ void ext_walk(const float* __restrict__ base, long long img_n, int w, int h, int j,
+                                         int jraw, bool lane_ok, int ibeg, int iend, int o, float thr_pre,
+                                         int emit_all, unsigned long long* __restrict__ kb, float* __restrict__ vb,
+                                         int* __restrict__ cnt, int cap, int& n_ext)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // column-adjacent blocks share cache lines at their boundary: keep them on one XCD
-    const unsigned vid = xcd_remap(blockIdx.x, nblocks);
-    const int bx = vid % nbx, by = (vid / nbx) % nby;
-    const long long b = vid / (nbx * nby);
-    const int seg = bx * 4 + wave;
-    const int jraw = seg * 62 + lane;                // lane 1 of seg 0 is column 1
-    const int ibeg = by * rows_per_wave + 1;          // first output row of the strip
-    const int iend = min(ibeg + rows_per_wave, h - 1);  // one past the last output row
-    if (seg * 62 + 1 > w - 2 || ibeg >= iend) return;  // wave-uniform
-    const int j = min(jraw, w - 1);
-    const bool lane_ok = lane >= 1 && lane <= 62 && jraw <= w - 2;
-    const float* base = dog + b * s_dog;
-    const long long img_n = (long long)w * h;
-    unsigned long long* kb = ckey + b * cap;
-    float* vb = cval + b * cap;
-    int* cnt = counters + b * SA_CNT_STRIDE;
-
     ExtWin<NDOG> W;
-    int n_ext = 0;
     // rows are fetched two steps ahead of their use so that two rows of loads are in flight
     float rawA[NDOG], rawB[NDOG];
     ext_fetch<NDOG>(rawA, base, img_n, (long long)(ibeg - 1) * w, j);
@@ -646,6 +640,61 @@ k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
         ext_load<NDOG, 1>(W, rawB);
         ext_eval<NDOG, 2, 0, 1>(W, lane_ok, o, i, jraw, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
         if (++i >= iend) break;
+    }
+}
+
+// `flags` (optional): marks of the 8-row x 64-column cells that hold a sample of a centre scale
+// passing the first contrast test (written by the blur).  A candidate's own sample must pass
+// that test, so rows whose cells are all unmarked are skipped; only maximal runs of marked row
+// groups are walked.  Without flags the whole strip is walked (needed when every discrete
+// extremum is to be listed or counted).
+template <int NDOG>
+__global__ void __launch_bounds__(256)
+k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
+          float thr_pre, int emit_all, int rows_per_wave,
+          unsigned long long* __restrict__ ckey, float* __restrict__ cval,
+          int* __restrict__ counters, int cap, int nbx, int nby, int nblocks,
+          const int* __restrict__ flags)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // column-adjacent blocks share cache lines at their boundary: keep them on one XCD
+    const unsigned vid = xcd_remap(blockIdx.x, nblocks);
+    const int bx = vid % nbx, by = (vid / nbx) % nby;
+    const long long b = vid / (nbx * nby);
+    const int seg = bx * 4 + wave;
+    const int jraw = seg * 62 + lane;                // lane 1 of seg 0 is column 1
+    const int ibeg = by * rows_per_wave + 1;          // first output row of the strip
+    const int iend = min(ibeg + rows_per_wave, h - 1);  // one past the last output row
+    if (seg * 62 + 1 > w - 2 || ibeg >= iend) return;  // wave-uniform
+    const int j = min(jraw, w - 1);
+    const bool lane_ok = lane >= 1 && lane <= 62 && jraw <= w - 2;
+    const float* base = dog + b * s_dog;
+    const long long img_n = (long long)w * h;
+    unsigned long long* kb = ckey + b * cap;
+    float* vb = cval + b * cap;
+    int* cnt = counters + b * SA_CNT_STRIDE;
+    int n_ext = 0;
+
+    if (!flags) {
+        ext_walk<NDOG>(base, img_n, w, h, j, jraw, lane_ok, ibeg, iend, o, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+    } else {
+        // bit g of `marked`: row group (ibeg>>3)+g has a marked cell under this wave's output columns
+        const int g0 = ibeg >> 3, ng = ((iend - 1) >> 3) - g0 + 1;
+        const int fw = (w + 63) >> 6;
+        const int c0 = (seg * 62 + 1) >> 6, c1 = min(seg * 62 + 62, w - 2) >> 6;
+        const int* frow = flags + (b * ((h + 7) >> 3) + g0) * (long long)fw;
+        int f = 0;                                  // lane g looks at row group g0+g (ng <= 33)
+        if (lane < ng) f = frow[(long long)lane * fw + c0] | frow[(long long)lane * fw + c1];
+        const unsigned long long marked = __ballot(f != 0);
+        int g = 0;
+        while (g < ng) {
+            if (!((marked >> g) & 1ull)) { ++g; continue; }
+            int ge = g;
+            while (ge + 1 < ng && ((marked >> (ge + 1)) & 1ull)) ++ge;
+            const int rb = max(ibeg, (g0 + g) << 3), re = min(iend, (g0 + ge + 1) << 3);
+            ext_walk<NDOG>(base, img_n, w, h, j, jraw, lane_ok, rb, re, o, thr_pre, emit_all, kb, vb, cnt, cap, n_ext);
+            g = ge + 1;
+        }
     }
     if (lane == 0 && n_ext) {
         atomicAdd(&cnt[SA_CNT_EXT_OCT + o], n_ext);
@@ -1403,12 +1452,14 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (forced > 0) strip = forced;
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
+    float* out = a.skip_out ? nullptr : a.out;
     if (a.ovs_w > 0)
-        HIPK((k_blur_fused<R, true, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta);
+        HIPK((k_blur_fused<R, true, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
+             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta,
+             a.flags, a.flag_thr);
     else
-        HIPK((k_blur_fused<R, false, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, a.out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, 0, 0, 0.f);
+        HIPK((k_blur_fused<R, false, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
+             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, 0, 0, 0.f, a.flags, a.flag_thr);
 }
 
 template <int R>
@@ -1499,7 +1550,7 @@ void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int 
 
 int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
                    float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
-                   int* counters, int cap, int batch)
+                   int* counters, int cap, int batch, const int* flags)
 {
     if (w < 3 || h < 3) return 0;
     static const int forced = getenv("SIFT_AMD_EXT_RPW") ? atoi(getenv("SIFT_AMD_EXT_RPW")) : 0;
@@ -1509,9 +1560,10 @@ int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int
     int rpw = 128;
     while (rpw > 16 && (long long)nseg * ((h - 2 + rpw - 1) / rpw) * batch < 2500) rpw >>= 1;
     if (forced > 0) rpw = forced;
+    if (rpw > 256) rpw = 256;   // the marked-cell mask of a strip has 64 bits (8 rows each)
     const int nbx = (nseg + 3) / 4, nby = (h - 2 + rpw - 1) / rpw, nblocks = nbx * nby * batch;
     dim3 grid(nblocks);
-#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap, nbx, nby, nblocks)
+#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap, nbx, nby, nblocks, flags)
     switch (n_dog) {
         case 3: EXT(3); break; case 4: EXT(4); break; case 5: EXT(5); break;
         case 6: EXT(6); break; case 7: EXT(7); break; case 8: EXT(8); break;

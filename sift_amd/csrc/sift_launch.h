@@ -23,6 +23,9 @@ struct BlurArgs {
     // the blur is its bilinear oversampling at step ovs_delta (w x h = oversampled size)
     int ovs_w = 0, ovs_h = 0;
     float ovs_delta = 0.f;
+    int* flags = nullptr;    // fused kernel only: marks of 8x64 cells holding a |DoG| sample > flag_thr
+    float flag_thr = 0.f;
+    bool skip_out = false;   // fused kernel only: do not store `out` (its DoG is all that is needed)
 };
 
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
@@ -37,7 +40,7 @@ void launch_sub(hipStream_t st, const float* a, const float* b, float* out, long
 void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int w, int h, int n_img);
 int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
                    float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
-                   int* counters, int cap, int batch);
+                   int* counters, int cap, int batch, const int* flags);
 void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,
                    const float* cval, int* counters, int cap, SaKey* ref, int* stage, int batch);
 void launch_rank(hipStream_t st, const unsigned long long* ckey, const int* stage, int* counters, int cap,

@@ -61,6 +61,10 @@ def test_batched_context_matches_single_images(hip):
         all_std, cnt2 = ctx.gather()
         assert np.array_equal(counts, cnt2) and len(all_std) == counts.sum()
         stage = [ctx.stage_counts(b) for b in range(n)]
+    with sift_amd.Context(w, h, max_batch=n, keep_all_extrema=True) as ctx:
+        ctx.detect_host(imgs)
+        stage_all = [ctx.stage_counts(b) for b in range(n)]
+        batch_all = [ctx.keypoints(b) for b in range(n)]
     off = 0
     for b in range(n):
         want = pyoracle.run(imgs[b], keep_ss=False)
@@ -71,10 +75,14 @@ def test_batched_context_matches_single_images(hip):
         assert np.abs(std["descriptor"].astype(np.int32) - want["keys"]["descr"].astype(np.int32)).max(initial=0) <= 1
         assert np.array_equal(all_std[off:off + counts[b]], std)
         off += counts[b]
-        sizes, ext = stage[b]
         n_oct = len(want["octaves"])
+        sizes, ext = stage_all[b]          # every discrete extremum listed: exact counts for A..F
         assert np.array_equal(ext, refrun.counts_per_octave(want["stages"]["A"]["ints"], n_oct))
         assert list(sizes) == [len(want["stages"][s]["ints"]) for s in "ABCDEF"]
+        sizes, ext = stage[b]              # throughput configuration: A is not counted, B..F are
+        assert sizes[0] == -1 and (ext == -1).all()
+        assert list(sizes[1:]) == [len(want["stages"][s]["ints"]) for s in "BCDEF"]
+        assert batch_all[b][0].tobytes() == std.tobytes() and batch_all[b][1].tobytes() == keys.tobytes()
 
 
 def test_run_to_run_determinism(hip):
