@@ -289,6 +289,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     c->sc.sigma_ratio = L->sigmas[0][1] / L->sigmas[0][0];              // lib_sift_anatomy.c:436
     c->sc.lambda_ori = p->lambda_ori; c->sc.t_peak = p->t; c->sc.lambda_descr = p->lambda_descr;
     c->sc.itermax = p->itermax; c->sc.n_bins = p->n_bins; c->sc.n_hist = p->n_hist; c->sc.n_ori = p->n_ori;
+    c->sc.debug = getenv("SIFT_AMD_DEBUG") ? atoi(getenv("SIFT_AMD_DEBUG")) : 0;
 
     // HBM pool
     const long long n0 = (long long)L->w[0] * L->h[0];

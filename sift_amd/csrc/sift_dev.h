@@ -66,6 +66,7 @@ struct SaScalars {
     float sigma_ratio;  // sigmas[0][1] / sigmas[0][0]
     float lambda_ori, t_peak, lambda_descr;
     int itermax, n_bins, n_hist, n_ori;
+    int debug;               // diagnostic switches (SIFT_AMD_DEBUG): 1 = generic descriptor list walk
 };
 
 #if defined(__HIPCC__)

@@ -309,11 +309,14 @@ __device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int w
 
 // OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
 // version at step `delta`, evaluated on the fly (w x h is the oversampled size).
+// Taps duplicated into pairs: packed multiplies take them straight from SGPR pairs.
+struct SaTapPairs { v2f g[SA_MAX_RADIUS_FAST + 1]; };
+
 template <int R, bool OVS, int EW, int NBUF>
 __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
-             long long s_dog, long long s_sub, SaTaps tp, int strip, int nbx, int nby, int nblocks,
+             long long s_dog, long long s_sub, SaTapPairs tp, int strip, int nbx, int nby, int nblocks,
              int wi, int hi, float delta, int* __restrict__ flags, float flag_thr)
 {
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
@@ -347,31 +350,44 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const bool vec_w = (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
 
+    // Column window of G + 2R samples, kept as register pairs so that two adjacent output rows
+    // are filtered by one packed instruction (v_pk_add_f32 / v_pk_mul_f32, IEEE like the scalar
+    // forms): wp[i] = {win[2i], win[2i+1]}, and per iteration wq[i] = {win[2i+1], win[2i+2]}.
     // Source rows are fetched one iteration (8 rows) ahead of their use.
-    float win[G + 2 * R];
+    constexpr int NP = (G + 2 * R) / 2;
+    v2f wp[NP];
     float nx[G];
 #pragma unroll
-    for (int t = 0; t < 2 * R; ++t) win[t] = load(i0 - R + t);
+    for (int t = 0; t < R; ++t) { wp[t].x = load(i0 - R + 2 * t); wp[t].y = load(i0 - R + 2 * t + 1); }
 #pragma unroll
     for (int g = 0; g < G; ++g) nx[g] = load(i0 + R + g);
+    // pair starting at window position a (compile-time constant after unrolling)
+#define SA_WPAIR(a) (((a) & 1) ? wq[((a) - 1) / 2] : wp[(a) / 2])
 
     int buf = 0;
     for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
+        for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nx[2 * q]; wp[R + q].y = nx[2 * q + 1]; }
+        // the odd pairs only live during the column pass (keeps the register peak down)
+        v2f wq[NP - 1];
+#pragma unroll
+        for (int t = 0; t < NP - 1; ++t) { wq[t].x = wp[t].y; wq[t].y = wp[t + 1].x; }
         if (ii + G < i1) {
 #pragma unroll
             for (int g = 0; g < G; ++g) nx[g] = load(ii + G + R + g);
         }
         if (NBUF == 1) __syncthreads();
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s = __fmul_rn(win[g + R], tp.g[0]);
+        for (int g = 0; g < G; g += 2) {
+            const v2f ctr = SA_WPAIR(g + R);
+            v2f s = ctr * tp.g[0];
 #pragma unroll
             for (int k = 1; k <= R; ++k)
-                s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[g + R - k], win[g + R + k])));
-            l_tmp[buf][g][tid] = s;
-            l_prev[buf][g][tid] = win[g + R];
+                s = s + tp.g[k] * (SA_WPAIR(g + R - k) + SA_WPAIR(g + R + k));
+            l_tmp[buf][g][tid] = s.x;
+            l_tmp[buf][g + 1][tid] = s.y;
+            l_prev[buf][g][tid] = ctr.x;
+            l_prev[buf][g + 1][tid] = ctr.y;
         }
         __syncthreads();
 #pragma unroll
@@ -390,10 +406,10 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 float o4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float s = __fmul_rn(hw[RP + q], tp.g[0]);
+                    float s = __fmul_rn(hw[RP + q], tp.g[0].x);
 #pragma unroll
                     for (int k = 1; k <= R; ++k)
-                        s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
+                        s = __fadd_rn(s, __fmul_rn(tp.g[k].x, __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
                     o4[q] = s;
                 }
                 const bool vec = vec_w && (xo + 4 <= w);
@@ -441,8 +457,9 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             }
         }
 #pragma unroll
-        for (int t = 0; t < 2 * R; ++t) win[t] = win[t + G];
+        for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
     }
+#undef SA_WPAIR
 }
 
 // Any radius (taps in global memory); one thread per output sample.  Only used for
@@ -1209,13 +1226,14 @@ k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const in
 // queued (in raster order) so that the expensive double-precision part always runs on full
 // waves.  Lane l owns the BPL consecutive descriptor bins l*BPL .. l*BPL+BPL-1.
 template <int BPL>
-__global__ void __launch_bounds__(64)
-k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
-                  int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
+__device__ __forceinline__ void
+descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
+                     int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
 {
     constexpr int POOL = 256;
-    __shared__ double p_cL[POOL], p_cR[POOL];
-    __shared__ int p_k[POOL];
+    // one slot of slack: the list walk reads one entry ahead
+    __shared__ __attribute__((aligned(16))) double p_c[POOL + 1][2];   // contribution to bin k0 / k0+1
+    __shared__ int p_k[POOL + 1];
     __shared__ int q_pix[128];
     __shared__ int cstart[SA_MAX_CELLS + 1];
     __shared__ float d_s[SA_MAX_DESCR];
@@ -1233,6 +1251,8 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
         my_k[u] = t % Nb;
         my_kprev[u] = my_k[u] == 0 ? Nb - 1 : my_k[u] - 1;
     }
+    // all bins of a lane lie in one cell (always true for the default 4x4x8 shape)
+    const bool one_cell = (Nb % BPL) == 0 && !(sc.debug & 1);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         const SaKey key = keys[b * kcap + q];
         const SaOctave& oc = P.oct[key.o];
@@ -1260,22 +1280,26 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
         for (int u = 0; u < BPL; ++u) acc[u] = 0.f;
 
         int qn = 0, p0 = 0;
+        // (row, column) inside the bounding box of raster position p0 + lane, advanced by 64
+        // positions per round without divisions
+        int fi = 0, fj = 0;
+        if (npix > 0) { fi = lane / nw; fj = lane - fi * nw; }
         while (p0 < npix || qn > 0) {
             // ---- queue the samples inside the rotated window, in raster order
             while (qn < 64 && p0 < npix) {
-                const int p = p0 + lane;
                 bool in_win = false;
-                if (p < npix) {
-                    const int si = i0 + p / nw, sj = j0 + p % nw;
-                    const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
+                if (p0 + lane < npix) {
+                    const float X0 = __fsub_rn((float)(i0 + fi), xk), Y0 = __fsub_rn((float)(j0 + fj), yk);
                     const float X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
                     const float Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
                     in_win = fmaxf(fabsf(X), fabsf(Y)) < R;
                 }
                 const unsigned long long m = __ballot(in_win);
-                if (in_win) q_pix[qn + __popcll(m & lt)] = p;
+                if (in_win) q_pix[qn + __popcll(m & lt)] = (fi << 16) | fj;
                 qn += __popcll(m);
                 p0 += 64;
+                fj += 64;
+                while (fj >= nw) { fj -= nw; ++fi; }
             }
             __syncthreads();
             const int nproc = min(qn, 64);
@@ -1285,7 +1309,7 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
             float X = 0.f, Y = 0.f, al = 0.f, be = 0.f;
             if (act) {
                 const int p = q_pix[lane];
-                si = i0 + p / nw; sj = j0 + p % nw;
+                si = i0 + (p >> 16); sj = j0 + (p & 0xffff);
                 const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
                 X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
                 Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
@@ -1296,8 +1320,9 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
             }
             int rank[4] = {0, 0, 0, 0};
             int cnt_mine = 0;                       // lane c < ncell keeps the size of list c
-            for (int c = 0; c < ncell; ++c) {
-                const int di = c / Nh - a0, dj = c % Nh - b0;
+            for (int c = 0, ci = 0, cj = 0; c < ncell; ++c, ++cj) {
+                if (cj == Nh) { cj = 0; ++ci; }
+                const int di = ci - a0, dj = cj - b0;
                 const bool f = act && (unsigned)di < 2u && (unsigned)dj < 2u;
                 const unsigned long long m = __ballot(f);
                 if (lane == c) cnt_mine = __popcll(m);
@@ -1339,26 +1364,48 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
                         const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
                         const int pos = cstart[ci * Nh + cj] + rank[sl];
                         p_k[pos] = k0;
-                        p_cL[pos] = wl * wa * wb * M;
-                        p_cR[pos] = wr * wa * wb * M;
+                        p_c[pos][0] = wl * wa * wb * M;
+                        p_c[pos][1] = wr * wa * wb * M;
                     }
                 }
             }
             __syncthreads();
             // ---- bin owners consume their cells' lists in order
+            if (one_cell) {
+                // Branch-free walk, next entry loaded while the current one is added.  An entry
+                // adds to at most one of a bin's two sources; the others add +0.0, which leaves
+                // the (non-negative) float accumulator unchanged bit for bit.
+                const int c = my_cell[0];
+                int e = 0, e1 = 0;
+                if (c >= 0) { e = cstart[c]; e1 = cstart[c + 1]; }
+                int kk = p_k[e];
+                double vL = p_c[e][0], vR = p_c[e][1];
+                while (e < e1) {
+                    const int nk = p_k[e + 1];
+                    const double nL = p_c[e + 1][0], nR = p_c[e + 1][1];
 #pragma unroll
-            for (int u = 0; u < BPL; ++u) {
-                if (u > 0 && my_cell[u] == my_cell[u - 1]) continue;   // handled with bin u-1
-                if (my_cell[u] < 0) continue;
-                const int e1 = cstart[my_cell[u] + 1];
-                for (int e = cstart[my_cell[u]]; e < e1; ++e) {
-                    const int kk = p_k[e];
-                    const double vL = p_cL[e], vR = p_cR[e];
+                    for (int v = 0; v < BPL; ++v) {
+                        const double add = kk == my_k[v] ? vL : (kk == my_kprev[v] ? vR : 0.0);
+                        acc[v] = (float)((double)acc[v] + add);
+                    }
+                    kk = nk; vL = nL; vR = nR;
+                    ++e;
+                }
+            } else {
 #pragma unroll
-                    for (int v = u; v < BPL; ++v) {
-                        if (my_cell[v] != my_cell[u]) break;
-                        if (kk == my_k[v]) acc[v] = (float)((double)acc[v] + vL);
-                        else if (kk == my_kprev[v]) acc[v] = (float)((double)acc[v] + vR);
+                for (int u = 0; u < BPL; ++u) {
+                    if (u > 0 && my_cell[u] == my_cell[u - 1]) continue;   // handled with bin u-1
+                    if (my_cell[u] < 0) continue;
+                    const int e1 = cstart[my_cell[u] + 1];
+                    for (int e = cstart[my_cell[u]]; e < e1; ++e) {
+                        const int kk = p_k[e];
+                        const double vL = p_c[e][0], vR = p_c[e][1];
+#pragma unroll
+                        for (int v = u; v < BPL; ++v) {
+                            if (my_cell[v] != my_cell[u]) break;
+                            if (kk == my_k[v]) acc[v] = (float)((double)acc[v] + vL);
+                            else if (kk == my_kprev[v]) acc[v] = (float)((double)acc[v] + vR);
+                        }
                     }
                 }
             }
@@ -1413,6 +1460,26 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
     }
 }
 
+template <int BPL>
+__global__ void __launch_bounds__(64)
+k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
+                  int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
+{
+    descriptor_wave_body<BPL>(P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+}
+
+// Same kernel compiled for a given number of resident waves per SIMD (register budget).
+#define SA_DESCR_WPE(N)                                                                                          \
+    __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N, N)))                             \
+    k_descriptor_wave2_wpe##N(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys,                         \
+                              const int* __restrict__ counters, int cnt_slot, int kcap,                          \
+                              SaStd* __restrict__ out_std, float* __restrict__ out_descr)                        \
+    {                                                                                                            \
+        descriptor_wave_body<2>(P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);                      \
+    }
+SA_DESCR_WPE(4)
+SA_DESCR_WPE(5)
+
 // ================================================================ launchers ==
 #define HIPK(...) do { hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
@@ -1453,13 +1520,15 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     if (forced > 0) strip = forced;
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
     float* out = a.skip_out ? nullptr : a.out;
+    SaTapPairs tp2;
+    for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
     if (a.ovs_w > 0)
         HIPK((k_blur_fused<R, true, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta,
+             a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta,
              a.flags, a.flag_thr);
     else
         HIPK((k_blur_fused<R, false, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, a.taps, strip, nbx, nby, nblocks, 0, 0, 0.f, a.flags, a.flag_thr);
+             a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, 0, 0, 0.f, a.flags, a.flag_thr);
 }
 
 template <int R>
@@ -1612,7 +1681,13 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
         const dim3 grid(4096, batch), blk(64);
         switch ((nd + 63) / 64) {
             case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
-            case 2: HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+            case 2: {
+                static const int wpe = getenv("SIFT_AMD_DESCR_WPE") ? atoi(getenv("SIFT_AMD_DESCR_WPE")) : 4;
+                if (wpe == 4) HIPK(k_descriptor_wave2_wpe4, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+                else if (wpe == 5) HIPK(k_descriptor_wave2_wpe5, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+                else HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+                break;
+            }
             case 3: HIPK(k_descriptor_wave<3>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
             default: HIPK(k_descriptor_wave<4>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
         }
