@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="diagnostic: images start in pinned host memory and are copied to the GPU "
                          "inside the timed region (PCIe-inclusive rate; not the headline value)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="contexts/streams used alternately (1 = strictly one batch at a time)")
     args = ap.parse_args()
 

@@ -1536,7 +1536,9 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
 {
     // wide tiles (480 outputs of 512 columns) halve the column halo; worth it on wide images
     static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 1 << 30;
+    static const int nbuf = getenv("SIFT_AMD_NBUF") ? atoi(getenv("SIFT_AMD_NBUF")) : 2;
     if (a.w >= wide_min) blur_fused_launch<R, 512, 1>(st, a);
+    else if (nbuf == 1) blur_fused_launch<R, 256, 1>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }
 
