@@ -93,3 +93,80 @@ def test_run_to_run_determinism(hip):
         ctx.detect_host(img)
         b = ctx.keypoints(0)[0].copy()
     assert a.tobytes() == b.tobytes()
+
+
+EDGE_IMAGES = {
+    "constant": lambda w, h: np.full((h, w), 0.37, np.float32),
+    "zeros": lambda w, h: np.zeros((h, w), np.float32),
+    "step": lambda w, h: np.tile((np.arange(w) >= w // 2).astype(np.float32), (h, 1)),
+    "impulse": lambda w, h: np.pad(np.ones((1, 1), np.float32), ((h // 2, h - h // 2 - 1), (w // 2, w - w // 2 - 1))),
+    "checker": lambda w, h: ((np.add.outer(np.arange(h) // 5, np.arange(w) // 7) & 1) * 0.8).astype(np.float32),
+}
+
+
+@pytest.mark.parametrize("name,w,h", [("constant", 96, 64), ("zeros", 64, 64), ("step", 100, 60),
+                                      ("impulse", 65, 49), ("checker", 150, 90), ("checker", 31, 203),
+                                      ("checker", 24, 24), ("impulse", 17, 13)])
+def test_degenerate_and_tiny_images(hip, name, w, h):
+    """Flat, binary and very small inputs (down to a single octave): stage sizes and final
+    records equal the oracle's, including the empty results."""
+    img = EDGE_IMAGES[name](w, h)
+    want = pyoracle.run(img, keep_ss=False)
+    with sift_amd.Context(w, h, keep_all_extrema=True) as ctx:
+        ctx.detect_host(img)
+        sizes, ext = ctx.stage_counts(0)
+        std, keys = ctx.keypoints(0)
+        _, descr, _ = ctx.extras(0)
+    n_oct = len(want["octaves"])
+    assert list(sizes) == [len(want["stages"][s]["ints"]) for s in "ABCDEF"]
+    assert np.array_equal(ext, refrun.counts_per_octave(want["stages"]["A"]["ints"], n_oct))
+    assert len(std) == len(want["keys"]["ints"])
+    if len(std):
+        got = np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1)
+        assert same_bits(got, want["keys"]["flts"][:, :4])
+        assert np.array_equal(descr, want["keys"]["descr"])
+    with sift_amd.Context(w, h) as ctx:           # throughput configuration: same records
+        ctx.detect_host(img)
+        std2, keys2 = ctx.keypoints(0)
+    assert std2.tobytes() == std.tobytes() and keys2.tobytes() == keys.tobytes()
+
+
+def test_partial_batches_and_context_reuse(hip):
+    """A context sized for 6 images run with 1, 6, then 3 images gives per-image results that
+    do not depend on the batch they were part of."""
+    w, h = 160, 120
+    imgs = np.stack([synth.make("white", w, h, seed=500 + b) for b in range(6)])
+    with sift_amd.Context(w, h, max_batch=6) as ctx:
+        ref = []
+        for b in range(6):
+            ctx.detect_host(imgs[b])
+            ref.append(ctx.keypoints(0)[0].copy())
+        ctx.detect_host(imgs)
+        for b in range(6):
+            assert ctx.keypoints(b)[0].tobytes() == ref[b].tobytes()
+        ctx.detect_host(imgs[[4, 1, 5]])
+        assert [ctx.keypoints(k)[0].tobytes() for k in range(3)] == [ref[b].tobytes() for b in (4, 1, 5)]
+        assert ctx.L.sift_amd_detect_host(ctx.ptr, imgs.ctypes.data_as(abi.c_float_p), 7) != 0   # over capacity
+
+
+def test_non_default_descriptor_shapes_and_matching_between_images(hip):
+    """n_hist x n_hist x n_ori other than 4x4x8 (bins of a lane straddling cells, float
+    descriptor path of the matcher)."""
+    w, h = 200, 150
+    a = synth.make("white", w, h, seed=71)
+    b = np.roll(a, (2, 3), axis=(0, 1))
+    for kw in ({"n_hist": 3, "n_ori": 8}, {"n_hist": 4, "n_ori": 5}, {"n_hist": 2, "n_ori": 12}):
+        p = _params(kw)
+        nd = p.n_hist * p.n_hist * p.n_ori
+        with sift_amd.Context(w, h, max_batch=2, params=p) as ctx:
+            ctx.detect_host(np.stack([a, b]))
+            d = [ctx.extras(k)[1] for k in range(2)]
+            m = ctx.match(0, 1, 0.7, 1)
+        for img, got in zip((a, b), d):
+            want = pyoracle.run(img, p, keep_ss=False)["keys"]["descr"]
+            assert got.shape == want.shape == (len(want), nd) and np.array_equal(got, want), kw
+        wm = pyoracle.matching(d[0], d[1], 0.7, 1)
+        for f in ("iA", "iB", "pass"):
+            assert np.array_equal(m[f], wm[f]), (kw, f)
+        assert np.array_equal(m["dA"].view(np.uint32), wm["dA"].view(np.uint32))
+        assert wm["pass"].sum() > 5

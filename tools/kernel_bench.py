@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--kind", default="smooth")
     ap.add_argument("--sigma-min", type=float, default=0.8)
     ap.add_argument("--sigma-in", type=float, default=0.5)
+    ap.add_argument("--roofline", action="store_true", help="print the per-kernel HBM roofline table")
     a = ap.parse_args()
     imgs = np.stack([synth.make(a.kind, a.w, a.h, 12345 + b) for b in range(min(a.batch, 4))])
     imgs = np.concatenate([imgs] * ((a.batch + len(imgs) - 1) // len(imgs)))[:a.batch]
@@ -57,6 +58,39 @@ def main():
         tot += ms / a.iters
         print(f"{api.KERNEL_CLASSES[c]:12s} {ms / a.iters:8.3f} ms/iter  ({n // a.iters} launches)  " + " ".join(per_oct))
     print(f"sum {tot:.3f} ms/iter for {a.batch} images -> {tot / a.batch * 1e3:.1f} us/image")
+    if a.roofline:
+        roofline_table(ctx, a)
+
+
+def roofline_table(ctx, a):
+    """Achieved algorithmic HBM GB/s per kernel class and octave against the 8 TB/s peak.
+
+    Algorithmic bytes per octave pixel (N_o pixels, B images): seed launch 5 (reads a quarter of
+    the pixels, writes one image); the n_sca-1 blur launches 12 each (read source, write Gaussian
+    and DoG image), -4 for the last one (its Gaussian image is not stored), +1 for the one that
+    also writes the next octave's first image; extrema scan 4 per DoG image.
+    """
+    B, ns = a.batch, ctx.n_sca
+    print()
+    print("| kernel class | octave | pixels/image | launches | ms/iter | algorithmic MB | GB/s | of 8 TB/s |")
+    print("|---|---:|---:|---:|---:|---:|---:|---:|")
+    for cls, name in ((api.K_OVERSAMPLE, "seed blur (oversampling fused)"), (api.K_BLUR_FUSED, "blur + DoG"),
+                      (api.K_EXTREMA, "extrema scan")):
+        for o in range(ctx.n_oct):
+            ms, n = ctx.profile_read(cls, o)
+            if not n:
+                continue
+            npx = ctx.dims[o][0] * ctx.dims[o][1]
+            if cls == api.K_OVERSAMPLE:
+                per_px = 5
+            elif cls == api.K_BLUR_FUSED:
+                per_px = 12 * (ns - 1) - 4 + (1 if o + 1 < ctx.n_oct else 0)
+            else:
+                per_px = 4 * (ns - 1)
+            mb = B * npx * per_px / 1e6
+            t = ms / a.iters
+            gbs = mb / 1e3 / (t * 1e-3)
+            print(f"| {name} | {o} | {npx} | {n // a.iters} | {t:.3f} | {mb:.1f} | {gbs:.0f} | {gbs / 8000:.2f} |")
 
 
 if __name__ == "__main__":
