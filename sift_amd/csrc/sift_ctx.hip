@@ -162,6 +162,7 @@ struct sift_amd_ctx {
     SaKey* d_keys = nullptr;
     int* d_key_src = nullptr;
     SaStd* d_std = nullptr;
+    SaStd* d_packed = nullptr;       // the batch's records without gaps between images (host gather)
     float* d_descr = nullptr;
     int* h_counters = nullptr;      // pinned
     bool counters_valid = false;
@@ -338,6 +339,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     if (dev_alloc(c, &c->d_keys, (size_t)(B * c->kcap))) return fail();
     if (dev_alloc(c, &c->d_key_src, (size_t)(B * c->kcap))) return fail();
     if (dev_alloc(c, &c->d_std, (size_t)(B * c->kcap))) return fail();
+    if (B > 1 && dev_alloc(c, &c->d_packed, (size_t)(B * c->kcap))) return fail();
     if (dev_alloc(c, &c->d_descr, (size_t)(B * c->kcap * SA_MAX_DESCR))) return fail();
     if (hipHostMalloc((void**)&c->h_counters, (size_t)B * SA_CNT_STRIDE * sizeof(int)) != hipSuccess) {
         sa_set_error("hipHostMalloc failed");
@@ -584,6 +586,7 @@ int sa_run_describe(sift_amd_ctx* c, int n, hipStream_t st)
 {
     ProfScope ps(c, st, SIFT_AMD_K_DESCRIPTOR, 0);
     sa::launch_descriptor(st, c->pyr, c->sc, c->d_keys, c->d_counters, SA_CNT_KEYS, c->kcap, c->d_std, c->d_descr, n);
+    if (n > 1) sa::launch_pack_std(st, c->d_std, c->d_counters, SA_CNT_KEYS, c->kcap, c->d_packed, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("descriptor launch failed: %s", hipGetErrorString(e)); return -1; }
     return 0;
@@ -775,13 +778,9 @@ extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** ou
     sift_keypoint_std* buf = (sift_keypoint_std*)malloc(std::max<size_t>(total, 1) * sizeof(sift_keypoint_std));
     if (!buf) { sa_set_error("out of host memory"); return -1; }
     hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
-    size_t off = 0;
-    for (int b = 0; b < c->last_n; b++) {
-        if (counts[b])
-            HIP_TRY(hipMemcpyAsync(buf + off, c->d_std + (size_t)b * c->kcap, (size_t)counts[b] * sizeof(SaStd),
-                                   hipMemcpyDeviceToHost, st));
-        off += counts[b];
-    }
+    // one copy: the records were packed image after image on the device (k_pack_std)
+    const SaStd* src = c->last_n > 1 ? c->d_packed : c->d_std;
+    if (total) HIP_TRY(hipMemcpyAsync(buf, src, total * sizeof(SaStd), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *out = buf;
     return 0;

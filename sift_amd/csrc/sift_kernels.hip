@@ -1480,6 +1480,24 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
 SA_DESCR_WPE(4)
 SA_DESCR_WPE(5)
 
+// Output records of a batch, image after image without gaps, so that the host gather is one
+// copy.  Block (x, b) copies a slice of image b's records to its offset (sum of the counts of
+// the images before it); 144-byte records move as 36 dwords.
+__global__ void __launch_bounds__(256)
+k_pack_std(const SaStd* __restrict__ std_recs, const int* __restrict__ counters, int cnt_slot, int kcap,
+           SaStd* __restrict__ packed)
+{
+    const int b = blockIdx.y;
+    int off = 0;
+    for (int k = 0; k < b; ++k) off += min(counters[k * SA_CNT_STRIDE + cnt_slot], kcap);
+    const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
+    const unsigned* src = reinterpret_cast<const unsigned*>(std_recs + (long long)b * kcap);
+    unsigned* dst = reinterpret_cast<unsigned*>(packed + off);
+    const long long words = (long long)n * (sizeof(SaStd) / 4);
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < words; t += (long long)gridDim.x * 256)
+        dst[t] = src[t];
+}
+
 // ================================================================ launchers ==
 #define HIPK(...) do { hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
@@ -1701,6 +1719,12 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
     else
         HIPK(k_descriptor<256>, dim3(1024, batch), dim3(256), 0, st, P, sc, keys, counters, cnt_slot, kcap,
              out_std, out_descr);
+}
+
+void launch_pack_std(hipStream_t st, const SaStd* std_recs, const int* counters, int cnt_slot, int kcap,
+                     SaStd* packed, int batch)
+{
+    HIPK(k_pack_std, dim3(32, batch), dim3(256), 0, st, std_recs, counters, cnt_slot, kcap, packed);
 }
 
 }  // namespace sa

@@ -55,4 +55,7 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
                        const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
                        int batch);
 
+void launch_pack_std(hipStream_t st, const SaStd* std_recs, const int* counters, int cnt_slot, int kcap,
+                     SaStd* packed, int batch);
+
 }  // namespace sa
