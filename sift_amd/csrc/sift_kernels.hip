@@ -357,10 +357,56 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     constexpr int NP = (G + 2 * R) / 2;
     v2f wp[NP];
     float nx[G];
+    // G consecutive source rows.  With the oversampling fused in and a step of exactly 1/2, rows
+    // 2m and 2m+1 of the oversampled image interpolate the same two input rows, so the
+    // horizontally interpolated input rows H[m] = fy*I[m][jp] + (1-fy)*I[m][jm] are computed once
+    // (5 or 6 of them per 8 rows) and every sample is fx*H[m+1] + (1-fx)*H[m]: the expressions
+    // and their order are those of ovs_sample, only shared.  Rows that need mirroring take the
+    // per-sample path.
+    const bool half_step = OVS && delta == 0.5f;
+    auto load_rows = [&](int ifirst, float* dst) {
+        if (OVS && half_step && ifirst >= 0 && ifirst + G - 1 < h && ((ifirst + G - 1) >> 1) + 1 < hi) {
+            const int m = ifirst >> 1;
+            const bool odd = ifirst & 1;
+            float H[G / 2 + 2];
 #pragma unroll
-    for (int t = 0; t < R; ++t) { wp[t].x = load(i0 - R + 2 * t); wp[t].y = load(i0 - R + 2 * t + 1); }
+            for (int t = 0; t < G / 2 + 2; ++t) {
+                H[t] = 0.f;
+                if (t < G / 2 + 1 || odd) {
+                    const float a = src[(long long)(m + t) * wi + oc.jp], b = src[(long long)(m + t) * wi + oc.jm];
+                    H[t] = __fadd_rn(__fmul_rn(oc.fy, a), __fmul_rn(1 - oc.fy, b));
+                }
+            }
+            if (odd) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) nx[g] = load(i0 + R + g);
+                for (int g = 0; g < G; ++g) {
+                    const int t = (g + 1) >> 1;
+                    const float fx = ((g + 1) & 1) ? 0.5f : 0.f;
+                    dst[g] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int t = g >> 1;
+                    const float fx = (g & 1) ? 0.5f : 0.f;
+                    dst[g] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) dst[g] = load(ifirst + g);
+        }
+    };
+    {
+        float pro[2 * R];
+#pragma unroll
+        for (int c = 0; c + G <= 2 * R; c += G) load_rows(i0 - R + c, &pro[c]);
+#pragma unroll
+        for (int t = (2 * R / G) * G; t < 2 * R; ++t) pro[t] = load(i0 - R + t);
+#pragma unroll
+        for (int t = 0; t < R; ++t) { wp[t].x = pro[2 * t]; wp[t].y = pro[2 * t + 1]; }
+    }
+    load_rows(i0 + R, nx);
     // pair starting at window position a (compile-time constant after unrolling)
 #define SA_WPAIR(a) (((a) & 1) ? wq[((a) - 1) / 2] : wp[(a) / 2])
 
@@ -372,10 +418,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         v2f wq[NP - 1];
 #pragma unroll
         for (int t = 0; t < NP - 1; ++t) { wq[t].x = wp[t].y; wq[t].y = wp[t + 1].x; }
-        if (ii + G < i1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) nx[g] = load(ii + G + R + g);
-        }
+        if (ii + G < i1) load_rows(ii + G + R, nx);
         if (NBUF == 1) __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; g += 2) {
