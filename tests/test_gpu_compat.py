@@ -169,3 +169,45 @@ def test_c_host_program_links_and_runs(hip, tmp_path):
     first = lines[0].split()
     assert first[:4] == ["%f" % v for v in want["keys"]["flts"][0, :4]]
     assert [int(v) for v in first[4:]] == want["keys"]["descr"][0].astype(int).tolist()
+
+
+def test_c_matching_host_program(hip, tmp_path):
+    """tests/c_host/match_example.c (the call sequence of match_cli.c) on two keypoint files
+    written in the reference's text format: the printed pairs are those of the oracle."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    a = synth.white(200, 150, 31)
+    b = np.roll(a, (3, 2), axis=(0, 1))
+    files, descr, xy = [], [], []
+    for k, img in enumerate((a, b)):
+        keys = api.sift_compute_features(img)
+        path = str(tmp_path / f"keys{k}.txt")
+        n = len(keys)
+        buf = keys.tobytes()
+        hip.sift_write_to_file(path.encode(), C.cast(C.c_char_p(buf), P(abi.SiftKeypointStd)), n)
+        files.append(path)
+        descr.append(keys["descriptor"].astype(np.float32))
+        xy.append(np.stack([keys["x"], keys["y"]], 1))
+    exe = str(tmp_path / "match_example")
+    libdir = os.path.join(root, "sift_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", os.path.join(root, "tests", "c_host", "match_example.c"),
+                           "-I", os.path.join(root, "include"), "-L", libdir, "-lsift_amd",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    res = subprocess.run([exe, files[0], files[1]], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    want = pyoracle.matching(descr[0], descr[1], 0.6, 1)
+    idx = np.nonzero(want["pass"])[0]
+    n1, n2, nm = [int(v) for v in res.stderr.split()[-3:]]
+    assert (n1, n2, nm) == (len(descr[0]), len(descr[1]), len(idx)) and nm > 10
+    rows = [l.split() for l in res.stdout.splitlines() if l.strip()]
+    assert len(rows) == nm
+    for row, i in zip(rows, idx):
+        # "x y sigma theta" of the query, then of its nearest neighbour (lib_keypoint.c:184-205)
+        vals = [float(v) for v in row]
+        assert vals[0] == float("%f" % xy[0][i, 0]) and vals[1] == float("%f" % xy[0][i, 1])
+        j = want["iA"][i]
+        assert vals[4] == float("%f" % xy[1][j, 0]) and vals[5] == float("%f" % xy[1][j, 1])
