@@ -1268,6 +1268,24 @@ k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const in
 // block-wide barriers are needed, and the samples that fall inside the rotated window are first
 // queued (in raster order) so that the expensive double-precision part always runs on full
 // waves.  Lane l owns the BPL consecutive descriptor bins l*BPL .. l*BPL+BPL-1.
+// array_l2norm (lib_util.c:156-164) over LDS by one lane: sequential float sum, four values
+// per LDS read.
+__device__ __forceinline__ float seq_l2norm(const float* d, int n)
+{
+    float l2 = 0.f;
+    int k = 0;
+#pragma unroll 8
+    for (; k + 4 <= n; k += 4) {
+        const v4f v = ld4(d + k);
+        l2 = __fadd_rn(l2, __fmul_rn(v.x, v.x));
+        l2 = __fadd_rn(l2, __fmul_rn(v.y, v.y));
+        l2 = __fadd_rn(l2, __fmul_rn(v.z, v.z));
+        l2 = __fadd_rn(l2, __fmul_rn(v.w, v.w));
+    }
+    for (; k < n; ++k) l2 = __fadd_rn(l2, __fmul_rn(d[k], d[k]));
+    return (float)sqrt((double)l2);
+}
+
 template <int BPL>
 __device__ __forceinline__ void
 descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
@@ -1279,7 +1297,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     __shared__ int p_k[POOL + 1];
     __shared__ int q_pix[128];
     __shared__ int cstart[SA_MAX_CELLS + 1];
-    __shared__ float d_s[SA_MAX_DESCR];
+    __shared__ __attribute__((aligned(16))) float d_s[SA_MAX_DESCR];
     __shared__ float norm_s;
     const int lane = threadIdx.x;
     const long long b = blockIdx.y;
@@ -1361,29 +1379,21 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 a0 = (int)floor((double)al);
                 b0 = (int)floor((double)be);
             }
-            int rank[4] = {0, 0, 0, 0};
-            int cnt_mine = 0;                       // lane c < ncell keeps the size of list c
+            // Rank of my sample in the list of each cell it touches (8 bits per slot, ranks < 64)
+            // and the start of every list: cells are visited in order, lane c remembers where
+            // list c starts, the running total is wave-uniform.
+            int rank_pack = 0, my_start = 0, run = 0;
             for (int c = 0, ci = 0, cj = 0; c < ncell; ++c, ++cj) {
                 if (cj == Nh) { cj = 0; ++ci; }
                 const int di = ci - a0, dj = cj - b0;
                 const bool f = act && (unsigned)di < 2u && (unsigned)dj < 2u;
                 const unsigned long long m = __ballot(f);
-                if (lane == c) cnt_mine = __popcll(m);
-                if (f) {
-                    const int r = __popcll(m & lt), sl = di * 2 + dj;
-                    if (sl == 0) rank[0] = r; else if (sl == 1) rank[1] = r;
-                    else if (sl == 2) rank[2] = r; else rank[3] = r;
-                }
+                if (lane == c) my_start = run;
+                if (f) rank_pack |= __popcll(m & lt) << (8 * (di * 2 + dj));
+                run += __popcll(m);
             }
-            {
-                int inc = cnt_mine;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int t = __shfl_up(inc, d);
-                    if (lane >= d) inc += t;
-                }
-                if (lane < ncell) cstart[lane] = inc - cnt_mine;
-                if (lane == ncell - 1) cstart[ncell] = inc;
-            }
+            if (lane < ncell) cstart[lane] = my_start;
+            if (lane == 0) cstart[ncell] = run;
             __syncthreads();
             // ---- contributions of my sample, appended to the lists of the cells it touches
             if (act) {
@@ -1405,7 +1415,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                         const float da = fabsf(__fsub_rn((float)ci, al));
                         const float db = fabsf(__fsub_rn((float)cj, be));
                         const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
-                        const int pos = cstart[ci * Nh + cj] + rank[sl];
+                        const int pos = cstart[ci * Nh + cj] + ((rank_pack >> (8 * sl)) & 0xff);
                         p_k[pos] = k0;
                         p_c[pos][0] = wl * wa * wb * M;
                         p_c[pos][1] = wr * wa * wb * M;
@@ -1466,11 +1476,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
         __syncthreads();
         // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
-        if (lane == 0) {
-            float l2 = 0.f;
-            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
-            norm_s = (float)sqrt((double)l2);
-        }
+        if (lane == 0) norm_s = seq_l2norm(d_s, nd);
         __syncthreads();
         const float cap = __fmul_rn(0.2f, norm_s);
 #pragma unroll
@@ -1479,11 +1485,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
         }
         __syncthreads();
-        if (lane == 0) {
-            float l2 = 0.f;
-            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
-            norm_s = (float)sqrt((double)l2);
-        }
+        if (lane == 0) norm_s = seq_l2norm(d_s, nd);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < BPL; ++u) {
