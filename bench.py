@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--kind", default="smooth", choices=["smooth", "white"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--host-input", action="store_true",
@@ -240,7 +240,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": traffic.get("bytes_per_launch") if traffic else None,
+                # PMC passes are taken at some batch size; HBM traffic of this kernel is proportional
+                # to the number of images per launch
+                "traffic": traffic["bytes_per_launch"] * B / traffic.get("images_per_launch", 16) if traffic else None,
                 "launches_timed": launches,
                 "measured": f"{roof_steps} extra steps right after the timed region, per-launch hipEvents",
                 "avg_launch_ms": (ms / launches) if launches else None,

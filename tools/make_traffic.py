@@ -6,7 +6,7 @@ MI355X counter notes prescribe: FETCH_SIZE (KiB) counts half of the bytes of coa
 reads on gfx950 (checked on this machine with tools/membench: dword and float4 reads of a known
 size both report exactly 1/2), WRITE_SIZE (KiB) is exact.
 
-    python tools/make_traffic.py gpurun_out/<tag> <blocks-of-the-octave-0-launch> [out.json]
+    python tools/make_traffic.py gpurun_out/<tag> <blocks-of-the-octave-0-launch (612 per 1080p image)> [out.json]
 """
 import collections
 import csv
@@ -29,6 +29,7 @@ def per_launch(tag, name, counter, kernel_substr, grid_threads):
 
 def main():
     tag, blocks = sys.argv[1], int(sys.argv[2])
+    images = blocks // 612          # a 1080p octave-0 launch has 18 x 34 blocks per image
     out = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
     grid = blocks * 256
     fetch_kib, n1 = per_launch(tag, "fetch", "FETCH_SIZE", "k_blur_fused", grid)
@@ -37,7 +38,7 @@ def main():
     rec = {"kernel": "k_blur_fused<R,false,...>, octave 0 launches (DoG-producing blurs)", "launches_sampled": [n1, n2],
            "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
            "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
-           "bytes_per_launch": rd + wr,
+           "bytes_per_launch": rd + wr, "images_per_launch": images,
            "correction": "read = 2 x FETCH_SIZE KiB (gfx950 counts 64 B per 128 B request), write = WRITE_SIZE KiB",
            "source": tag}
     json.dump(rec, open(out, "w"), indent=1)

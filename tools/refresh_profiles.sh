@@ -14,6 +14,6 @@ python3 tools/prof_summary.py $OUT/stats 33 > $OUT/kernel_stats.md
 python3 tools/trace_by_grid.py $OUT/stats "" 40 > $OUT/by_grid.txt
 bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc k_blur_fused > $OUT/pmc_blur.txt
-python3 tools/make_traffic.py $OUT/pmc 9792 $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
+python3 tools/make_traffic.py $OUT/pmc 39168 $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo done
