@@ -406,19 +406,66 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
         for (int t = 0; t < R; ++t) { wp[t].x = pro[2 * t]; wp[t].y = pro[2 * t + 1]; }
     }
-    load_rows(i0 + R, nx);
+    // Prefetch of the next G rows, split in two so that the loads stay in flight during a whole
+    // iteration: `issue` starts them (fast path: the raw input samples of the shared rows),
+    // `finish` interpolates at the top of the next iteration.
+    float raw[OVS ? 2 * (G / 2 + 2) : 1];
+    bool raw_pending = false, raw_odd = false;
+    auto issue_rows = [&](int ifirst) {
+        if (OVS && half_step && ifirst >= 0 && ifirst + G - 1 < h && ((ifirst + G - 1) >> 1) + 1 < hi) {
+            const int m = ifirst >> 1;
+            raw_odd = ifirst & 1;
+#pragma unroll
+            for (int t = 0; t < G / 2 + 2; ++t) {
+                // the last row is only needed for an odd start; reading row m+t <= hi-1 is always in range
+                const int row = min(m + t, hi - 1);
+                raw[2 * t] = src[(long long)row * wi + oc.jp];
+                raw[2 * t + 1] = src[(long long)row * wi + oc.jm];
+            }
+            raw_pending = true;
+        } else {
+            raw_pending = false;
+#pragma unroll
+            for (int g = 0; g < G; ++g) nx[g] = load(ifirst + g);
+        }
+    };
+    auto finish_rows = [&]() {
+        if (!OVS || !raw_pending) return;
+        float H[G / 2 + 2];
+#pragma unroll
+        for (int t = 0; t < G / 2 + 2; ++t)
+            H[t] = __fadd_rn(__fmul_rn(oc.fy, raw[OVS ? 2 * t : 0]), __fmul_rn(1 - oc.fy, raw[OVS ? 2 * t + 1 : 0]));
+        if (raw_odd) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int t = (g + 1) >> 1;
+                const float fx = ((g + 1) & 1) ? 0.5f : 0.f;
+                nx[g] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int t = g >> 1;
+                const float fx = (g & 1) ? 0.5f : 0.f;
+                nx[g] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+            }
+        }
+        raw_pending = false;
+    };
+    issue_rows(i0 + R);
     // pair starting at window position a (compile-time constant after unrolling)
 #define SA_WPAIR(a) (((a) & 1) ? wq[((a) - 1) / 2] : wp[(a) / 2])
 
     int buf = 0;
     for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
+        finish_rows();
 #pragma unroll
         for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nx[2 * q]; wp[R + q].y = nx[2 * q + 1]; }
         // the odd pairs only live during the column pass (keeps the register peak down)
         v2f wq[NP - 1];
 #pragma unroll
         for (int t = 0; t < NP - 1; ++t) { wq[t].x = wp[t].y; wq[t].y = wp[t + 1].x; }
-        if (ii + G < i1) load_rows(ii + G + R, nx);
+        if (ii + G < i1) issue_rows(ii + G + R);
         if (NBUF == 1) __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; g += 2) {
