@@ -986,6 +986,14 @@ __device__ __forceinline__ float modulus_f(float x, float y)   // lib_util.c:187
     return z;
 }
 
+// (k + n) % n (lib_description.c:331) without the division for the values that occur
+// (k in [-n, 2n)); anything else takes the modulo.
+__device__ __forceinline__ int wrap_bin(int k, int n)
+{
+    if ((unsigned)(k + n) < (unsigned)(3 * n)) return k < 0 ? k + n : (k >= n ? k - n : k);
+    return (k + n) % n;
+}
+
 __device__ __forceinline__ float bin_to_ori(float bin, int nbins)   // lib_description.c:88-94
 {
     float ori = (float)(((double)bin + 0.5) * 2 * SA_PI / (double)(float)nbins);
@@ -1214,7 +1222,7 @@ k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const in
                     a0 = (int)floor((double)al);
                     b0 = (int)floor((double)be);
                     const double gf = floor((double)ga);
-                    k0 = ((int)ga + Nb) % Nb;
+                    k0 = wrap_bin((int)ga, Nb);
                     const double wl = 1. - ((double)ga - gf);
                     const double wr = 1.0 - (gf + 1 - (double)ga);
 #pragma unroll
@@ -1344,6 +1352,10 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     __shared__ int p_k[POOL + 1];
     __shared__ int q_pix[128];
     __shared__ int cstart[SA_MAX_CELLS + 1];
+    // per-bin lists (n_ori <= 64): list starts, and per batch the lane mask of every cell and
+    // of every orientation-bin pair
+    __shared__ int bstart_s[SA_MAX_DESCR];
+    __shared__ unsigned long long cm_s[SA_MAX_CELLS], kk_s[64], pa_s[16], pb_s[16];
     __shared__ __attribute__((aligned(16))) float d_s[SA_MAX_DESCR];
     __shared__ float norm_s;
     const int lane = threadIdx.x;
@@ -1361,6 +1373,10 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     }
     // all bins of a lane lie in one cell (always true for the default 4x4x8 shape)
     const bool one_cell = (Nb % BPL) == 0 && !(sc.debug & 1);
+    // One list per descriptor bin instead of one per cell: a lane then touches only the
+    // contributions of its own bins.  Needs a lane per orientation bin for the bookkeeping.
+    const bool bin_lists = Nb <= 64 && !(sc.debug & 2);
+    double* pool = &p_c[0][0];                 // 2*(POOL+1) doubles: up to 512 contributions + slack
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         const SaKey key = keys[b * kcap + q];
         const SaOctave& oc = P.oct[key.o];
@@ -1426,85 +1442,204 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 a0 = (int)floor((double)al);
                 b0 = (int)floor((double)be);
             }
-            // Rank of my sample in the list of each cell it touches (8 bits per slot, ranks < 64)
-            // and the start of every list: cells are visited in order, lane c remembers where
-            // list c starts, the running total is wave-uniform.
-            int rank_pack = 0, my_start = 0, run = 0;
-            for (int c = 0, ci = 0, cj = 0; c < ncell; ++c, ++cj) {
-                if (cj == Nh) { cj = 0; ++ci; }
-                const int di = ci - a0, dj = cj - b0;
-                const bool f = act && (unsigned)di < 2u && (unsigned)dj < 2u;
-                const unsigned long long m = __ballot(f);
-                if (lane == c) my_start = run;
-                if (f) rank_pack |= __popcll(m & lt) << (8 * (di * 2 + dj));
-                run += __popcll(m);
-            }
-            if (lane < ncell) cstart[lane] = my_start;
-            if (lane == 0) cstart[ncell] = run;
-            __syncthreads();
-            // ---- contributions of my sample, appended to the lists of the cells it touches
-            if (act) {
-                const double dx = (double)grad_i(im, w, h, si, sj);
-                const double dy = (double)grad_j(im, w, h, si, sj);
-                float ori = (float)(atan2(dy, dx) - (double)theta);
-                ori = modulus_f(ori, (float)(2 * SA_PI));
-                const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
-                const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
-                const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
-                const double gf = floor((double)ga);
-                const int k0 = ((int)ga + Nb) % Nb;
-                const double wl = 1. - ((double)ga - gf);
-                const double wr = 1.0 - (gf + 1 - (double)ga);
+            if (bin_lists) {
+                // ---- my sample's orientation bin pair, weights and magnitude
+                int k0 = 0, k1 = 0;
+                double wl = 0., wr = 0., M = 0.;
+                if (act) {
+                    const double dx = (double)grad_i(im, w, h, si, sj);
+                    const double dy = (double)grad_j(im, w, h, si, sj);
+                    float ori = (float)(atan2(dy, dx) - (double)theta);
+                    ori = modulus_f(ori, (float)(2 * SA_PI));
+                    const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
+                    M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
+                    const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                    const double gf = floor((double)ga);
+                    k0 = wrap_bin((int)ga, Nb);
+                    k1 = k0 + 1 == Nb ? 0 : k0 + 1;
+                    wl = 1. - ((double)ga - gf);
+                    wr = 1.0 - (gf + 1 - (double)ga);
+                }
+                // ---- kk_s[k]: lanes whose sample adds to orientation bin k (its own bin k0 == k,
+                // or k0 == k-1 through the second weight); lane k collects the mask of k0 == k
+                unsigned long long myK = 0;
+                for (int k = 0; k < Nb; ++k) {
+                    const unsigned long long m = __ballot(act && k0 == k);
+                    if (lane == k) myK = m;
+                }
+                {
+                    const int src = lane == 0 ? Nb - 1 : lane - 1;
+                    const unsigned lo = __shfl((unsigned)myK, src), hi = __shfl((unsigned)(myK >> 32), src);
+                    if (lane < Nb) kk_s[lane] = myK | (((unsigned long long)hi << 32) | lo);
+                }
+                __syncthreads();
+                unsigned long long mA = 0, mB = 0;
+                if (act) { mA = kk_s[k0]; mB = kk_s[k1]; }
+                // ---- which samples touch which cell: a sample with corner (a0, b0) touches the cell
+                // rows a0, a0+1 and columns b0, b0+1, so the mask of cell (ci, cj) is
+                // (samples with a0 in {ci-1, ci}) & (samples with b0 in {cj-1, cj}).  Lane p collects
+                // the mask of a0 == p-1 (p = 0..Nh), pa_s[p] is the pair mask of cell row p-1.
+                {
+                    unsigned long long tA = 0, tB = 0;
+                    for (int a = -1; a < Nh; ++a) {
+                        const unsigned long long ma_ = __ballot(act && a0 == a), mb_ = __ballot(act && b0 == a);
+                        if (lane == a + 1) { tA = ma_; tB = mb_; }
+                    }
+                    const int src = lane == 0 ? 63 : lane - 1;     // lane 63 holds 0 (Nh <= 8)
+                    const unsigned long long pA = ((unsigned long long)__shfl((unsigned)(tA >> 32), src) << 32) | __shfl((unsigned)tA, src);
+                    const unsigned long long pB = ((unsigned long long)__shfl((unsigned)(tB >> 32), src) << 32) | __shfl((unsigned)tB, src);
+                    if (lane <= Nh + 1) { pa_s[lane] = tA | pA; pb_s[lane] = tB | pB; }
+                }
+                __syncthreads();
+                // ranks of my two contributions inside every cell I touch (8 bits per slot)
+                int rankL = 0, rankR = 0;
+                if (act) {
+                    const unsigned long long ra0 = pa_s[a0 + 1], ra1 = pa_s[a0 + 2];
+                    const unsigned long long rb0 = pb_s[b0 + 1], rb1 = pb_s[b0 + 2];
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
-                    if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
-                        const float da = fabsf(__fsub_rn((float)ci, al));
-                        const float db = fabsf(__fsub_rn((float)cj, be));
-                        const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
-                        const int pos = cstart[ci * Nh + cj] + ((rank_pack >> (8 * sl)) & 0xff);
-                        p_k[pos] = k0;
-                        p_c[pos][0] = wl * wa * wb * M;
-                        p_c[pos][1] = wr * wa * wb * M;
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const unsigned long long m = ((sl >> 1) ? ra1 : ra0) & ((sl & 1) ? rb1 : rb0) & lt;
+                        rankL |= __popcll(m & mA) << (8 * sl);
+                        rankR |= __popcll(m & mB) << (8 * sl);
                     }
                 }
-            }
-            __syncthreads();
-            // ---- bin owners consume their cells' lists in order
-            if (one_cell) {
-                // Branch-free walk, next entry loaded while the current one is added.  An entry
-                // adds to at most one of a bin's two sources; the others add +0.0, which leaves
-                // the (non-negative) float accumulator unchanged bit for bit.
-                const int c = my_cell[0];
-                int e = 0, e1 = 0;
-                if (c >= 0) { e = cstart[c]; e1 = cstart[c + 1]; }
-                int kk = p_k[e];
-                double vL = p_c[e][0], vR = p_c[e][1];
-                while (e < e1) {
-                    const int nk = p_k[e + 1];
-                    const double nL = p_c[e + 1][0], nR = p_c[e + 1][1];
-#pragma unroll
-                    for (int v = 0; v < BPL; ++v) {
-                        const double add = kk == my_k[v] ? vL : (kk == my_kprev[v] ? vR : 0.0);
-                        acc[v] = (float)((double)acc[v] + add);
-                    }
-                    kk = nk; vL = nL; vR = nR;
-                    ++e;
+                if (lane < ncell) {
+                    const int ci = lane / Nh, cj = lane - ci * Nh;
+                    cm_s[lane] = pa_s[ci + 1] & pb_s[cj + 1];
                 }
-            } else {
+                __syncthreads();
+                // ---- list length of my bins, list starts by a scan in bin order
+                int cnt[BPL], start[BPL], tot = 0;
 #pragma unroll
                 for (int u = 0; u < BPL; ++u) {
-                    if (u > 0 && my_cell[u] == my_cell[u - 1]) continue;   // handled with bin u-1
-                    if (my_cell[u] < 0) continue;
-                    const int e1 = cstart[my_cell[u] + 1];
-                    for (int e = cstart[my_cell[u]]; e < e1; ++e) {
-                        const int kk = p_k[e];
-                        const double vL = p_c[e][0], vR = p_c[e][1];
+                    cnt[u] = my_cell[u] >= 0 ? __popcll(cm_s[my_cell[u]] & kk_s[my_k[u]]) : 0;
+                    start[u] = tot;
+                    tot += cnt[u];
+                }
+                {
+                    int inc = tot;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const int t = __shfl_up(inc, d);
+                        if (lane >= d) inc += t;
+                    }
+                    const int excl = inc - tot;
 #pragma unroll
-                        for (int v = u; v < BPL; ++v) {
-                            if (my_cell[v] != my_cell[u]) break;
-                            if (kk == my_k[v]) acc[v] = (float)((double)acc[v] + vL);
-                            else if (kk == my_kprev[v]) acc[v] = (float)((double)acc[v] + vR);
+                    for (int u = 0; u < BPL; ++u) {
+                        start[u] += excl;
+                        if (my_cell[u] >= 0) bstart_s[lane * BPL + u] = start[u];
+                    }
+                }
+                __syncthreads();
+                // ---- my contributions go to their places in the lists
+                if (act) {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
+                        if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
+                            const float da = fabsf(__fsub_rn((float)ci, al));
+                            const float db = fabsf(__fsub_rn((float)cj, be));
+                            const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
+                            const int base = (ci * Nh + cj) * Nb;
+                            pool[bstart_s[base + k0] + ((rankL >> (8 * sl)) & 0xff)] = wl * wa * wb * M;
+                            pool[bstart_s[base + k1] + ((rankR >> (8 * sl)) & 0xff)] = wr * wa * wb * M;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- every lane adds the lists of its bins, in order, next value loaded ahead
+#pragma unroll
+                for (int u = 0; u < BPL; ++u) {
+                    int e = start[u];
+                    const int e1 = e + cnt[u];
+                    double v = pool[e];
+                    while (e < e1) {
+                        const double nv = pool[e + 1];
+                        acc[u] = (float)((double)acc[u] + v);
+                        v = nv;
+                        ++e;
+                    }
+                }
+            } else {
+                // Rank of my sample in the list of each cell it touches (8 bits per slot, ranks < 64)
+                // and the start of every list: cells are visited in order, lane c remembers where
+                // list c starts, the running total is wave-uniform.
+                int rank_pack = 0, my_start = 0, run = 0;
+                for (int c = 0, ci = 0, cj = 0; c < ncell; ++c, ++cj) {
+                    if (cj == Nh) { cj = 0; ++ci; }
+                    const int di = ci - a0, dj = cj - b0;
+                    const bool f = act && (unsigned)di < 2u && (unsigned)dj < 2u;
+                    const unsigned long long m = __ballot(f);
+                    if (lane == c) my_start = run;
+                    if (f) rank_pack |= __popcll(m & lt) << (8 * (di * 2 + dj));
+                    run += __popcll(m);
+                }
+                if (lane < ncell) cstart[lane] = my_start;
+                if (lane == 0) cstart[ncell] = run;
+                __syncthreads();
+                // ---- contributions of my sample, appended to the lists of the cells it touches
+                if (act) {
+                    const double dx = (double)grad_i(im, w, h, si, sj);
+                    const double dy = (double)grad_j(im, w, h, si, sj);
+                    float ori = (float)(atan2(dy, dx) - (double)theta);
+                    ori = modulus_f(ori, (float)(2 * SA_PI));
+                    const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
+                    const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
+                    const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                    const double gf = floor((double)ga);
+                    const int k0 = wrap_bin((int)ga, Nb);
+                    const double wl = 1. - ((double)ga - gf);
+                    const double wr = 1.0 - (gf + 1 - (double)ga);
+    #pragma unroll
+                    for (int sl = 0; sl < 4; ++sl) {
+                        const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
+                        if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
+                            const float da = fabsf(__fsub_rn((float)ci, al));
+                            const float db = fabsf(__fsub_rn((float)cj, be));
+                            const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
+                            const int pos = cstart[ci * Nh + cj] + ((rank_pack >> (8 * sl)) & 0xff);
+                            p_k[pos] = k0;
+                            p_c[pos][0] = wl * wa * wb * M;
+                            p_c[pos][1] = wr * wa * wb * M;
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---- bin owners consume their cells' lists in order
+                if (one_cell) {
+                    // Branch-free walk, next entry loaded while the current one is added.  An entry
+                    // adds to at most one of a bin's two sources; the others add +0.0, which leaves
+                    // the (non-negative) float accumulator unchanged bit for bit.
+                    const int c = my_cell[0];
+                    int e = 0, e1 = 0;
+                    if (c >= 0) { e = cstart[c]; e1 = cstart[c + 1]; }
+                    int kk = p_k[e];
+                    double vL = p_c[e][0], vR = p_c[e][1];
+                    while (e < e1) {
+                        const int nk = p_k[e + 1];
+                        const double nL = p_c[e + 1][0], nR = p_c[e + 1][1];
+    #pragma unroll
+                        for (int v = 0; v < BPL; ++v) {
+                            const double add = kk == my_k[v] ? vL : (kk == my_kprev[v] ? vR : 0.0);
+                            acc[v] = (float)((double)acc[v] + add);
+                        }
+                        kk = nk; vL = nL; vR = nR;
+                        ++e;
+                    }
+                } else {
+    #pragma unroll
+                    for (int u = 0; u < BPL; ++u) {
+                        if (u > 0 && my_cell[u] == my_cell[u - 1]) continue;   // handled with bin u-1
+                        if (my_cell[u] < 0) continue;
+                        const int e1 = cstart[my_cell[u] + 1];
+                        for (int e = cstart[my_cell[u]]; e < e1; ++e) {
+                            const int kk = p_k[e];
+                            const double vL = p_c[e][0], vR = p_c[e][1];
+    #pragma unroll
+                            for (int v = u; v < BPL; ++v) {
+                                if (my_cell[v] != my_cell[u]) break;
+                                if (kk == my_k[v]) acc[v] = (float)((double)acc[v] + vL);
+                                else if (kk == my_kprev[v]) acc[v] = (float)((double)acc[v] + vR);
+                            }
                         }
                     }
                 }

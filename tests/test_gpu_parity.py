@@ -155,7 +155,8 @@ def test_non_default_descriptor_shapes_and_matching_between_images(hip):
     w, h = 200, 150
     a = synth.make("white", w, h, seed=71)
     b = np.roll(a, (2, 3), axis=(0, 1))
-    for kw in ({"n_hist": 3, "n_ori": 8}, {"n_hist": 4, "n_ori": 5}, {"n_hist": 2, "n_ori": 12}):
+    for kw in ({"n_hist": 3, "n_ori": 8}, {"n_hist": 4, "n_ori": 5}, {"n_hist": 2, "n_ori": 12},
+               {"n_hist": 1, "n_ori": 72}, {"n_hist": 2, "n_ori": 64}):
         p = _params(kw)
         nd = p.n_hist * p.n_hist * p.n_ori
         with sift_amd.Context(w, h, max_batch=2, params=p) as ctx:
