@@ -187,18 +187,18 @@ def main():
         # Dominant kernel: the Gaussian blur with DoG epilogue on octave 0 (n_sca-1 = 5 launches per
         # step; the seed launch, which evaluates the bilinear oversampling on the fly and writes no
         # DoG, is a different instantiation and is timed separately).
-        # Algorithmic bytes per octave-0 pixel and launch, fused kernel: read the source image (4 B),
-        # write the blurred image (4 B) and the DoG image (4 B) = 12 B; the launch that also emits
-        # the next octave's first image adds 1 B (a quarter of the pixels); the last launch does not
-        # store its blurred image (only its DoG is used), 4 B less.
+        # Algorithmic bytes per octave-0 pixel and launch, fused kernel: read the source image (4 B)
+        # and write the blurred image (4 B) = 8 B (DoG images are not stored: the extrema scan and
+        # the refinement form DoG values from the Gaussian stack); the launch that also emits the
+        # next octave's first image adds 1 B (a quarter of the pixels).
         # Two-kernel form, row pass: read column-pass image and previous Gaussian image, write
         # Gaussian and DoG image = 16 B.
         n0 = ctx.dims[0][0] * ctx.dims[0][1]
         ms, launches = ctx.profile_read(dom, 0)
         per_step = ctx.n_sca - 1
         if fused:
-            bytes_per_step = B * n0 * (12 * (ctx.n_sca - 1) - 4 + (1 if ctx.n_oct > 1 else 0))
-            kname = "k_blur_fused<R,false> (column+row pass, DoG epilogue), octave 0, R = 5,7,8,10,13"
+            bytes_per_step = B * n0 * (8 * (ctx.n_sca - 1) + (1 if ctx.n_oct > 1 else 0))
+            kname = "k_blur_fused<R,false> (column+row pass, contrast marks), octave 0, R = 5,7,8,10,13"
         else:
             per_step = ctx.n_sca                     # the seed row pass is timed in the same class
             bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))

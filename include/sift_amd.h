@@ -168,9 +168,10 @@ typedef struct sift_amd_ctx sift_amd_ctx;
 enum {
     SIFT_AMD_KEEP_ALL_EXTREMA = 1, /* list every discrete extremum (needed to reproduce kk[0]);
                                       default keeps only those passing the first contrast test */
-    SIFT_AMD_KEEP_SCALESPACE = 2   /* store every Gaussian image; by default the last one of each
-                                      octave, which only its DoG needs, is never written
-                                      (required by sift_amd_copy_scalespace(which = 0)) */
+    SIFT_AMD_KEEP_SCALESPACE = 2   /* also store the DoG images; by default they never exist in
+                                      memory (the scan and the refinement form DoG values from
+                                      the Gaussian stack); required by
+                                      sift_amd_copy_scalespace(which = 1) */
 };
 
 /* Kernel classes for the built-in event timers. */

@@ -304,7 +304,9 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     for (int o = 0; o < L->n_oct; o++) {
         const long long n = (long long)L->w[o] * L->h[o];
         if (dev_alloc(c, &c->d_gss[o], (size_t)(B * L->n_sca * n))) return fail();
-        if (dev_alloc(c, &c->d_dog[o], (size_t)(B * (L->n_sca - 1) * n))) return fail();
+        // DoG images exist in memory only for callers that download them; the pipeline itself
+        // forms DoG values from the Gaussian stack where it needs them
+        if ((flags & SIFT_AMD_KEEP_SCALESPACE) && dev_alloc(c, &c->d_dog[o], (size_t)(B * (L->n_sca - 1) * n))) return fail();
         SaOctave& oc = c->pyr.oct[o];
         oc.gss = c->d_gss[o]; oc.dog = c->d_dog[o];
         oc.gss_stride = L->n_sca * n; oc.dog_stride = (L->n_sca - 1) * n;
@@ -522,16 +524,14 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 sub = c->d_gss[o + 1];
                 s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
             }
-            // the last Gaussian image is read by nothing but its own DoG (keypoints live on scales
-            // 1..n_spo): it is stored only for callers that download the scale-space
-            const bool skip = s == ns - 1 && !(c->flags & SIFT_AMD_KEEP_SCALESPACE);
+            const bool skip = false;
             // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
             int* cells = nullptr;
             if (mark && s - 1 >= 1 && s - 1 <= ns - 3) {
                 if (c->step[o][s].radius >= 1 && c->step[o][s].radius <= SA_MAX_RADIUS_FAST) cells = c->d_cells[o];
                 else c->cells_valid[o] = false;
             }
-            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d + (s - 1) * np, sd, sub, s_sub, n,
+            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d ? d + (s - 1) * np : nullptr, sd, sub, s_sub, n,
                      0, 0, 0.f, skip, cells);
         }
     }
@@ -548,7 +548,7 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
     for (int o = 0; o < L.n_oct; o++) {
         const long long np = (long long)L.w[o] * L.h[o];
         ProfScope ps(c, st, SIFT_AMD_K_EXTREMA, o);
-        if (sa::launch_extrema(st, c->d_dog[o], (L.n_sca - 1) * np, L.w[o], L.h[o], L.n_sca - 1, o,
+        if (sa::launch_extrema(st, c->d_gss[o], L.n_sca * np, L.w[o], L.h[o], L.n_sca - 1, o,
                                c->sc.thr_pre, emit_all, c->d_ckey, c->d_cval, c->d_counters, c->cap, n,
                                c->cells_valid[o] && !emit_all ? c->d_cells[o] : nullptr)) {
             sa_set_error("unsupported number of DoG images %d", L.n_sca - 1);
@@ -845,8 +845,8 @@ extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int
         sa_set_error("bad image/octave/which");
         return -1;
     }
-    if (which == 0 && !(c->flags & SIFT_AMD_KEEP_SCALESPACE)) {
-        sa_set_error("the Gaussian stack is only complete in a context created with SIFT_AMD_KEEP_SCALESPACE");
+    if (which == 1 && !(c->flags & SIFT_AMD_KEEP_SCALESPACE)) {
+        sa_set_error("DoG images are only stored in a context created with SIFT_AMD_KEEP_SCALESPACE");
         return -1;
     }
     HIP_TRY(hipSetDevice(c->device));

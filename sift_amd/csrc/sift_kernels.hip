@@ -287,8 +287,8 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
 // sample exceeds flag_thr in magnitude (cells [image][row/8][col/64]); the extrema scan skips
 // unmarked cells.
 // `sub`, if given, receives the even samples (the next octave's first image,
-// lib_discrete.c:180-191).  `out` may be null: the last Gaussian image of an octave is only
-// needed for its DoG, so the fast path does not store it.
+// lib_discrete.c:180-191).  `dog` may be null: the pipeline forms DoG values from the Gaussian
+// stack where it needs them and stores DoG images only for callers that download them.
 // Source sample (i, col) of the fused blur when the source is the bilinearly oversampled
 // input (OVS): same expression and operation order as k_oversample / lib_discrete.c:207-237.
 struct OvsCol { int jm, jp; float fy; };
@@ -476,8 +476,10 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 s = s + tp.g[k] * (SA_WPAIR(g + R - k) + SA_WPAIR(g + R + k));
             l_tmp[buf][g][tid] = s.x;
             l_tmp[buf][g + 1][tid] = s.y;
-            l_prev[buf][g][tid] = ctr.x;
-            l_prev[buf][g + 1][tid] = ctr.y;
+            if (dog || flags) {          // unfiltered centre samples, for the DoG epilogue
+                l_prev[buf][g][tid] = ctr.x;
+                l_prev[buf][g + 1][tid] = ctr.y;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -514,17 +516,19 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                             if (xo + q < w) po[q] = o4[q];
                     }
                 }
-                if (dog) {
+                if (dog || flags) {
                     const v4f pv = ld4(&l_prev[buf][hg][RP + 4 * hq]);
-                    float* pd = dog + b * s_dog + off;
                     const float d4[4] = {__fsub_rn(o4[0], pv.x), __fsub_rn(o4[1], pv.y),
                                          __fsub_rn(o4[2], pv.z), __fsub_rn(o4[3], pv.w)};
-                    if (vec) {
-                        st4(pd, d4[0], d4[1], d4[2], d4[3]);
-                    } else {
+                    if (dog) {
+                        float* pd = dog + b * s_dog + off;
+                        if (vec) {
+                            st4(pd, d4[0], d4[1], d4[2], d4[3]);
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (xo + q < w) pd[q] = d4[q];
+                            for (int q = 0; q < 4; ++q)
+                                if (xo + q < w) pd[q] = d4[q];
+                        }
                     }
                     // mark the 8-row x 64-column cell if a sample passes the first contrast test
                     // (columns past w hold mirrored data and only ever add marks)
@@ -637,21 +641,24 @@ struct ExtWin {
     float C[NDOG - 2][3], EM[NDOG - 2][3], Em[NDOG - 2][3];  // centre, max/min of (left,right)
 };
 
+// The DoG images are not read from memory: the scan fetches the NDOG+1 Gaussian samples of a
+// row and forms dog[d] = gss[d+1] - gss[d] (lib_sift_anatomy.c:169-186, one float subtraction,
+// same bits as a stored DoG image) when the row is consumed.
 template <int NDOG>
-__device__ __forceinline__ void ext_fetch(float (&raw)[NDOG], const float* __restrict__ base,
+__device__ __forceinline__ void ext_fetch(float (&raw)[NDOG + 1], const float* __restrict__ base,
                                           long long img_n, long long off, int j)
 {
     // base/img_n/off are wave-uniform, j is the lane's column: scalar base + 32-bit lane offset
 #pragma unroll
-    for (int d = 0; d < NDOG; ++d) raw[d] = (base + d * img_n + off)[j];
+    for (int d = 0; d <= NDOG; ++d) raw[d] = (base + d * img_n + off)[j];
 }
 
 template <int NDOG, int SLOT>
-__device__ __forceinline__ void ext_load(ExtWin<NDOG>& W, const float (&raw)[NDOG])
+__device__ __forceinline__ void ext_load(ExtWin<NDOG>& W, const float (&raw)[NDOG + 1])
 {
 #pragma unroll
     for (int d = 0; d < NDOG; ++d) {
-        const float v = raw[d];
+        const float v = __fsub_rn(raw[d + 1], raw[d]);
         const float l = lane_prev(v), r = lane_next(v);
         W.M3[d][SLOT] = max3f(l, v, r);
         W.N3[d][SLOT] = min3f(l, v, r);
@@ -714,7 +721,7 @@ __device__ __forceinline__ void ext_walk(const float* __restrict__ base, long lo
 {
     ExtWin<NDOG> W;
     // rows are fetched two steps ahead of their use so that two rows of loads are in flight
-    float rawA[NDOG], rawB[NDOG];
+    float rawA[NDOG + 1], rawB[NDOG + 1];
     ext_fetch<NDOG>(rawA, base, img_n, (long long)(ibeg - 1) * w, j);
     ext_fetch<NDOG>(rawB, base, img_n, (long long)ibeg * w, j);
     ext_load<NDOG, 0>(W, rawA);
@@ -757,7 +764,7 @@ __device__ __forceinline__ void ext_walk(const float* __restrict__ base, long lo
 // extremum is to be listed or counted).
 template <int NDOG>
 __global__ void __launch_bounds__(256)
-k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
+k_extrema(const float* __restrict__ gss, long long s_gss, int w, int h, int o,
           float thr_pre, int emit_all, int rows_per_wave,
           unsigned long long* __restrict__ ckey, float* __restrict__ cval,
           int* __restrict__ counters, int cap, int nbx, int nby, int nblocks,
@@ -775,7 +782,7 @@ k_extrema(const float* __restrict__ dog, long long s_dog, int w, int h, int o,
     if (seg * 62 + 1 > w - 2 || ibeg >= iend) return;  // wave-uniform
     const int j = min(jraw, w - 1);
     const bool lane_ok = lane >= 1 && lane <= 62 && jraw <= w - 2;
-    const float* base = dog + b * s_dog;
+    const float* base = gss + b * s_gss;
     const long long img_n = (long long)w * h;
     unsigned long long* kb = ckey + b * cap;
     float* vb = cval + b * cap;
@@ -816,7 +823,9 @@ __device__ __forceinline__ void taylor3d(const float* __restrict__ st, int w, in
                                          float& oX, float& oY, float& oS, float& val)
 {
     const long long n = (long long)w * h;
-#define D(ss, ii, jj) st[(long long)(ss) * n + (long long)(ii) * w + (jj)]
+    // dog[s] = gss[s+1] - gss[s], formed on the fly (st is the Gaussian stack)
+#define D(ss, ii, jj) __fsub_rn(st[(long long)((ss) + 1) * n + (long long)(ii) * w + (jj)], \
+                                st[(long long)(ss) * n + (long long)(ii) * w + (jj)])
     const float c = D(s, i, j);
     const float c2 = __fmul_rn(2.f, c);
     const float hXX = __fsub_rn(__fadd_rn(D(s, i - 1, j), D(s, i + 1, j)), c2);
@@ -867,7 +876,7 @@ k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
         const SaOctave& oc = P.oct[o];
         const int w = oc.w, h = oc.h, ns = P.n_sca - 1;
         const float delta = oc.delta;
-        const float* st = oc.dog + b * oc.dog_stride;
+        const float* st = oc.gss + b * oc.gss_stride;      // Gaussian stack; DoG formed on the fly
         float val = cval[b * cap + c];
         SaKey k;
         k.o = o; k.s = s0; k.i = i0; k.j = j0;
@@ -905,14 +914,15 @@ k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
                 k.val = val;
                 if (fabsf(val) > sc.thr) {
                     stg = SA_ST_D; ++nD;
-                    const float* im = st + (long long)scur * w * h;
-                    const float c0 = im[(long long)ic * w + jc];
+                    const float* g0 = st + (long long)scur * w * h;
+                    const float* g1 = g0 + (long long)w * h;
+                    auto dg = [&](int ii, int jj) { return __fsub_rn(g1[(long long)ii * w + jj], g0[(long long)ii * w + jj]); };
+                    const float c0 = dg(ic, jc);
                     const float c2 = __fmul_rn(2.f, c0);
-                    const float hXX = __fsub_rn(__fadd_rn(im[(long long)(ic - 1) * w + jc], im[(long long)(ic + 1) * w + jc]), c2);
-                    const float hYY = __fsub_rn(__fadd_rn(im[(long long)ic * w + jc + 1], im[(long long)ic * w + jc - 1]), c2);
-                    const float hXY = __fmul_rn(0.25f, __fsub_rn(
-                        __fsub_rn(im[(long long)(ic + 1) * w + jc + 1], im[(long long)(ic + 1) * w + jc - 1]),
-                        __fsub_rn(im[(long long)(ic - 1) * w + jc + 1], im[(long long)(ic - 1) * w + jc - 1])));
+                    const float hXX = __fsub_rn(__fadd_rn(dg(ic - 1, jc), dg(ic + 1, jc)), c2);
+                    const float hYY = __fsub_rn(__fadd_rn(dg(ic, jc + 1), dg(ic, jc - 1)), c2);
+                    const float hXY = __fmul_rn(0.25f, __fsub_rn(__fsub_rn(dg(ic + 1, jc + 1), dg(ic + 1, jc - 1)),
+                                                                __fsub_rn(dg(ic - 1, jc + 1), dg(ic - 1, jc - 1))));
                     const float tr = __fadd_rn(hXX, hYY);
                     k.edge = __fdiv_rn(__fmul_rn(tr, tr), __fsub_rn(__fmul_rn(hXX, hYY), __fmul_rn(hXY, hXY)));
                     if (fabsf(k.edge) <= sc.thr_edge) {
@@ -1864,7 +1874,7 @@ void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int 
     HIPK(k_gradient, grid, dim3(256), 0, st, im, gi, gj, w, h, n_img);
 }
 
-int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
+int launch_extrema(hipStream_t st, const float* gss, long long s_gss, int w, int h, int n_dog, int o,
                    float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
                    int* counters, int cap, int batch, const int* flags)
 {
@@ -1879,7 +1889,7 @@ int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int
     if (rpw > 256) rpw = 256;   // the marked-cell mask of a strip has 64 bits (8 rows each)
     const int nbx = (nseg + 3) / 4, nby = (h - 2 + rpw - 1) / rpw, nblocks = nbx * nby * batch;
     dim3 grid(nblocks);
-#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, dog, s_dog, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap, nbx, nby, nblocks, flags)
+#define EXT(N) HIPK(k_extrema<N>, grid, dim3(256), 0, st, gss, s_gss, w, h, o, thr_pre, emit_all, rpw, ckey, cval, counters, cap, nbx, nby, nblocks, flags)
     switch (n_dog) {
         case 3: EXT(3); break; case 4: EXT(4); break; case 5: EXT(5); break;
         case 6: EXT(6); break; case 7: EXT(7); break; case 8: EXT(8); break;

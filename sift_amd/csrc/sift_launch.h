@@ -38,7 +38,7 @@ void launch_subsample(hipStream_t st, const float* in, int wi, long long s_in,
 void launch_sub(hipStream_t st, const float* a, const float* b, float* out, long long n,
                 long long s_a, long long s_b, long long s_out, int batch);
 void launch_gradient(hipStream_t st, const float* im, float* gi, float* gj, int w, int h, int n_img);
-int launch_extrema(hipStream_t st, const float* dog, long long s_dog, int w, int h, int n_dog, int o,
+int launch_extrema(hipStream_t st, const float* gss, long long s_gss, int w, int h, int n_dog, int o,
                    float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
                    int* counters, int cap, int batch, const int* flags);
 void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,

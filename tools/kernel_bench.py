@@ -66,15 +66,15 @@ def roofline_table(ctx, a):
     """Achieved algorithmic HBM GB/s per kernel class and octave against the 8 TB/s peak.
 
     Algorithmic bytes per octave pixel (N_o pixels, B images): seed launch 5 (reads a quarter of
-    the pixels, writes one image); the n_sca-1 blur launches 12 each (read source, write Gaussian
-    and DoG image), -4 for the last one (its Gaussian image is not stored), +1 for the one that
-    also writes the next octave's first image; extrema scan 4 per DoG image.
+    the pixels, writes one image); the n_sca-1 blur launches 8 each (read source, write Gaussian
+    image; DoG images are not stored), +1 for the one that also writes the next octave's first
+    image; extrema scan 4 per Gaussian image (it forms the DoG values itself).
     """
     B, ns = a.batch, ctx.n_sca
     print()
     print("| kernel class | octave | pixels/image | launches | ms/iter | algorithmic MB | GB/s | of 8 TB/s |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|")
-    for cls, name in ((api.K_OVERSAMPLE, "seed blur (oversampling fused)"), (api.K_BLUR_FUSED, "blur + DoG"),
+    for cls, name in ((api.K_OVERSAMPLE, "seed blur (oversampling fused)"), (api.K_BLUR_FUSED, "blur (+ marks)"),
                       (api.K_EXTREMA, "extrema scan")):
         for o in range(ctx.n_oct):
             ms, n = ctx.profile_read(cls, o)
@@ -84,9 +84,9 @@ def roofline_table(ctx, a):
             if cls == api.K_OVERSAMPLE:
                 per_px = 5
             elif cls == api.K_BLUR_FUSED:
-                per_px = 12 * (ns - 1) - 4 + (1 if o + 1 < ctx.n_oct else 0)
+                per_px = 8 * (ns - 1) + (1 if o + 1 < ctx.n_oct else 0)
             else:
-                per_px = 4 * (ns - 1)
+                per_px = 4 * ns
             mb = B * npx * per_px / 1e6
             t = ms / a.iters
             gbs = mb / 1e3 / (t * 1e-3)
