@@ -191,8 +191,7 @@ def main():
         # and write the blurred image (4 B) = 8 B (DoG images are not stored: the extrema scan and
         # the refinement form DoG values from the Gaussian stack); the launch that also emits the
         # next octave's first image adds 1 B (a quarter of the pixels).
-        # Two-kernel form, row pass: read column-pass image and previous Gaussian image, write
-        # Gaussian and DoG image = 16 B.
+        # Two-kernel form, row pass: read the column-pass image, write the Gaussian image = 8 B.
         n0 = ctx.dims[0][0] * ctx.dims[0][1]
         ms, launches = ctx.profile_read(dom, 0)
         per_step = ctx.n_sca - 1
@@ -201,7 +200,7 @@ def main():
             kname = "k_blur_fused<R,false> (column+row pass, contrast marks), octave 0, R = 5,7,8,10,13"
         else:
             per_step = ctx.n_sca                     # the seed row pass is timed in the same class
-            bytes_per_step = B * n0 * (8 + 16 * (ctx.n_sca - 1))
+            bytes_per_step = B * n0 * 8 * ctx.n_sca
             kname = "k_blur_h (row pass + DoG epilogue), octave 0"
         steps_timed = launches / per_step if per_step else 0
         achieved = (bytes_per_step * steps_timed) / (ms * 1e-3) / 1e9 if ms > 0 else None

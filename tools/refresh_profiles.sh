@@ -12,6 +12,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 cd $ROOT
 python3 tools/prof_summary.py $OUT/stats 33 > $OUT/kernel_stats.md
 python3 tools/trace_by_grid.py $OUT/stats "" 40 > $OUT/by_grid.txt
+python3 tools/dominant_from_trace.py $OUT/stats 39168 50 > $OUT/dominant_kernel_rocprof.txt
 bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc k_blur_fused > $OUT/pmc_blur.txt
 python3 tools/make_traffic.py $OUT/pmc 39168 $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
