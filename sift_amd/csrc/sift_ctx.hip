@@ -462,10 +462,9 @@ extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, doubl
 
 static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
                      float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n,
-                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, bool skip_out = false, int* cells = nullptr)
+                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, int* cells = nullptr)
 {
     sa::BlurArgs a;
-    a.skip_out = skip_out;
     a.flags = cells; a.flag_thr = c->sc.thr_pre;
     a.ovs_w = ovs_w; a.ovs_h = ovs_h; a.ovs_delta = ovs_delta;
     a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog; a.sub = sub;
@@ -524,7 +523,6 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 sub = c->d_gss[o + 1];
                 s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
             }
-            const bool skip = false;
             // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
             int* cells = nullptr;
             if (mark && s - 1 >= 1 && s - 1 <= ns - 3) {
@@ -532,7 +530,7 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 else c->cells_valid[o] = false;
             }
             run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d ? d + (s - 1) * np : nullptr, sd, sub, s_sub, n,
-                     0, 0, 0.f, skip, cells);
+                     0, 0, 0.f, cells);
         }
     }
     hipError_t e = hipGetLastError();

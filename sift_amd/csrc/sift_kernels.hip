@@ -1774,7 +1774,7 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (forced > 0) strip = forced;
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
-    float* out = a.skip_out ? nullptr : a.out;
+    float* out = a.out;
     SaTapPairs tp2;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
     if (a.ovs_w > 0)

@@ -25,7 +25,6 @@ struct BlurArgs {
     float ovs_delta = 0.f;
     int* flags = nullptr;    // fused kernel only: marks of 8x64 cells holding a |DoG| sample > flag_thr
     float flag_thr = 0.f;
-    bool skip_out = false;   // fused kernel only: do not store `out` (its DoG is all that is needed)
 };
 
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
