@@ -1789,10 +1789,14 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
 template <int R>
 static void blur_fused_t(hipStream_t st, const BlurArgs& a)
 {
-    // wide tiles (480 outputs of 512 columns) halve the column halo; worth it on wide images
-    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 1 << 30;
+    // wide tiles (480 outputs of 512 columns, 8 waves) halve the relative column halo and the idle
+    // row-pass slots: worth ~5 % where the arithmetic co-limits and the image is wide enough to
+    // keep all CUs busy (octave 0 of a 1080p image and up)
+    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 3000;
+    static const int wide_nbuf = getenv("SIFT_AMD_WIDE_NBUF") ? atoi(getenv("SIFT_AMD_WIDE_NBUF")) : 2;
     static const int nbuf = getenv("SIFT_AMD_NBUF") ? atoi(getenv("SIFT_AMD_NBUF")) : 2;
-    if (a.w >= wide_min) blur_fused_launch<R, 512, 1>(st, a);
+    if (a.w >= wide_min && wide_nbuf == 2) blur_fused_launch<R, 512, 2>(st, a);
+    else if (a.w >= wide_min) blur_fused_launch<R, 512, 1>(st, a);
     else if (nbuf == 1) blur_fused_launch<R, 256, 1>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }
