@@ -312,7 +312,7 @@ __device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int w
 // Taps duplicated into pairs: packed multiplies take them straight from SGPR pairs.
 struct SaTapPairs { v2f g[SA_MAX_RADIUS_FAST + 1]; };
 
-template <int R, bool OVS, int EW, int NBUF>
+template <int R, bool OVS, int EW, int NBUF, bool VW>
 __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
@@ -347,7 +347,8 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     };
     const int i0 = by * strip;
     const int i1 = min(i0 + strip, h);
-    const bool vec_w = (w & 3) == 0;
+    // VW: the launcher guarantees w % 4 == 0, every 4-sample item is then a whole 16-byte access
+    const bool vec_w = VW || (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
 
     // Column window of G + 2R samples, kept as register pairs so that two adjacent output rows
@@ -504,7 +505,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                         s = __fadd_rn(s, __fmul_rn(tp.g[k].x, __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
                     o4[q] = s;
                 }
-                const bool vec = vec_w && (xo + 4 <= w);
+                const bool vec = VW || (vec_w && (xo + 4 <= w));
                 const long long off = (long long)row * w + xo;
                 if (out) {
                     float* po = out + b * s_out + off;
@@ -540,7 +541,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 }
                 if (sub && !(row & 1) && (row >> 1) < ho) {
                     float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
-                    if (((wo & 1) == 0) && (xo >> 1) + 2 <= wo) {
+                    if (VW || (((wo & 1) == 0) && (xo >> 1) + 2 <= wo)) {
                         v2f v = {o4[0], o4[2]};
                         *reinterpret_cast<v2f*>(__builtin_assume_aligned(ps, 8)) = v;
                     } else {
@@ -1777,13 +1778,18 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     float* out = a.out;
     SaTapPairs tp2;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
-    if (a.ovs_w > 0)
-        HIPK((k_blur_fused<R, true, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h, a.ovs_delta,
-             a.flags, a.flag_thr);
-    else
-        HIPK((k_blur_fused<R, false, EW, NBUF>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h,
-             a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, 0, 0, 0.f, a.flags, a.flag_thr);
+#define SA_BLUR_LAUNCH(OVS_, VW_, ...)                                                                       \
+    HIPK((k_blur_fused<R, OVS_, EW, NBUF, VW_>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h, \
+         a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, __VA_ARGS__, a.flags, a.flag_thr)
+    const bool vw = (a.w & 3) == 0;
+    if (a.ovs_w > 0) {
+        if (vw) SA_BLUR_LAUNCH(true, true, a.ovs_w, a.ovs_h, a.ovs_delta);
+        else SA_BLUR_LAUNCH(true, false, a.ovs_w, a.ovs_h, a.ovs_delta);
+    } else {
+        if (vw) SA_BLUR_LAUNCH(false, true, 0, 0, 0.f);
+        else SA_BLUR_LAUNCH(false, false, 0, 0, 0.f);
+    }
+#undef SA_BLUR_LAUNCH
 }
 
 template <int R>
@@ -1793,11 +1799,7 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
     // row-pass slots: worth ~5 % where the arithmetic co-limits and the image is wide enough to
     // keep all CUs busy (octave 0 of a 1080p image and up)
     static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 3000;
-    static const int wide_nbuf = getenv("SIFT_AMD_WIDE_NBUF") ? atoi(getenv("SIFT_AMD_WIDE_NBUF")) : 2;
-    static const int nbuf = getenv("SIFT_AMD_NBUF") ? atoi(getenv("SIFT_AMD_NBUF")) : 2;
-    if (a.w >= wide_min && wide_nbuf == 2) blur_fused_launch<R, 512, 2>(st, a);
-    else if (a.w >= wide_min) blur_fused_launch<R, 512, 1>(st, a);
-    else if (nbuf == 1) blur_fused_launch<R, 256, 1>(st, a);
+    if (a.w >= wide_min) blur_fused_launch<R, 512, 2>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }
 
