@@ -172,3 +172,20 @@ def test_non_default_descriptor_shapes_and_matching_between_images(hip):
             assert np.array_equal(m[f], wm[f]), (kw, f)
         assert np.array_equal(m["dA"].view(np.uint32), wm["dA"].view(np.uint32))
         assert wm["pass"].sum() > 5
+
+
+@pytest.mark.parametrize("kw,needle", [
+    ({"sigma_min": 0.3}, "sigma_min"), ({"delta_min": 1.5}, "delta_min"), ({"n_spo": 10}, "n_spo"),
+    ({"n_bins": 70}, "n_bins"), ({"n_hist": 9}, "n_hist"), ({"n_ori": 1}, "n_ori"),
+    ({"n_hist": 8, "n_ori": 8}, "n_hist")])
+def test_unsupported_parameters_are_refused_with_a_message(hip, kw, needle):
+    """The batched interface reports bad parameters through its error channel (the reference
+    asserts); nothing is launched."""
+    with pytest.raises(sift_amd.api.SiftAmdError) as e:
+        sift_amd.Context(128, 96, params=_params(kw))
+    assert needle in str(e.value)
+
+
+def test_image_too_small_for_one_octave_is_refused(hip):
+    with pytest.raises(sift_amd.api.SiftAmdError):
+        sift_amd.Context(4, 4)
