@@ -105,11 +105,20 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
+    # SIFT_AMD_BENCH_REHEARSAL=1: every rank uses GPU 0 and the ranks meet over gloo, to rehearse
+    # the multi-process path on a one-GPU machine (not a measurement)
+    rehearsal = os.environ.get("SIFT_AMD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if rehearsal else "cuda"
 
     B = args.batch
     # shard of the synthetic batch owned by this rank: image b of rank r has seed 12345 + r*B + b
@@ -175,8 +184,8 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_enable([])
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    nk = torch.tensor([float(counts.sum())], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    nk = torch.tensor([float(counts.sum())], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(nk, op=dist.ReduceOp.SUM)
