@@ -6,7 +6,7 @@ MI355X counter notes prescribe: FETCH_SIZE (KiB) counts half of the bytes of coa
 reads on gfx950 (checked on this machine with tools/membench: dword and float4 reads of a known
 size both report exactly 1/2), WRITE_SIZE (KiB) is exact.
 
-    python tools/make_traffic.py gpurun_out/<tag> <blocks-of-the-octave-0-launch (612 per 1080p image)> [out.json]
+    python tools/make_traffic.py gpurun_out/<tag> <threads of the octave-0 launch> <images per launch> [out.json]
 """
 import collections
 import csv
@@ -28,10 +28,8 @@ def per_launch(tag, name, counter, kernel_substr, grid_threads):
 
 
 def main():
-    tag, blocks = sys.argv[1], int(sys.argv[2])
-    images = blocks // 612          # a 1080p octave-0 launch has 18 x 34 blocks per image
-    out = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
-    grid = blocks * 256
+    tag, grid, images = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    out = sys.argv[4] if len(sys.argv) > 4 else "profiles/traffic.json"
     fetch_kib, n1 = per_launch(tag, "fetch", "FETCH_SIZE", "k_blur_fused", grid)
     write_kib, n2 = per_launch(tag, "write", "WRITE_SIZE", "k_blur_fused", grid)
     rd, wr = 2.0 * fetch_kib * 1024, write_kib * 1024
