@@ -307,10 +307,30 @@ __device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int w
     return __fadd_rn(__fmul_rn(fx, top), __fmul_rn(1 - fx, bot));
 }
 
-// OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
-// version at step `delta`, evaluated on the fly (w x h is the oversampled size).
+// Sum of the window pairs that start at positions a and b (same parity; compile-time constants
+// after unrolling) of a window held as register pairs p[i] = {win[2i], win[2i+1]}.  Aligned
+// positions take one packed add; odd positions take two plain adds on the halves, which costs
+// the same issue time on gfx950 (a packed f32 instruction occupies the VALU about twice as long
+// as a plain one) and needs no register moves to line the operands up.
+__device__ __forceinline__ v2f win_pair_sum(const v2f* p, int a, int b)
+{
+    if (!(a & 1)) return p[a / 2] + p[b / 2];
+    v2f t;
+    t.x = __fadd_rn(p[(a - 1) / 2].y, p[(b - 1) / 2].y);
+    t.y = __fadd_rn(p[(a + 1) / 2].x, p[(b + 1) / 2].x);
+    return t;
+}
+// the pair starting at position a
+__device__ __forceinline__ v2f win_pair(const v2f* p, int a)
+{
+    if (!(a & 1)) return p[a / 2];
+    return v2f{p[(a - 1) / 2].y, p[(a + 1) / 2].x};
+}
 // Taps duplicated into pairs: packed multiplies take them straight from SGPR pairs.
 struct SaTapPairs { v2f g[SA_MAX_RADIUS_FAST + 1]; };
+
+// OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
+// version at step `delta`, evaluated on the fly (w x h is the oversampled size).
 
 template <int R, bool OVS, int EW, int NBUF, bool VW>
 __global__ void __launch_bounds__(EW)
@@ -353,7 +373,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 
     // Column window of G + 2R samples, kept as register pairs so that two adjacent output rows
     // are filtered by one packed instruction (v_pk_add_f32 / v_pk_mul_f32, IEEE like the scalar
-    // forms): wp[i] = {win[2i], win[2i+1]}, and per iteration wq[i] = {win[2i+1], win[2i+2]}.
+    // forms): wp[i] = {win[2i], win[2i+1]}; see win_pair_sum for the taps at odd offsets.
     // Source rows are fetched one iteration (8 rows) ahead of their use.
     constexpr int NP = (G + 2 * R) / 2;
     v2f wp[NP];
@@ -454,27 +474,21 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         raw_pending = false;
     };
     issue_rows(i0 + R);
-    // pair starting at window position a (compile-time constant after unrolling)
-#define SA_WPAIR(a) (((a) & 1) ? wq[((a) - 1) / 2] : wp[(a) / 2])
 
     int buf = 0;
     for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
         finish_rows();
 #pragma unroll
         for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nx[2 * q]; wp[R + q].y = nx[2 * q + 1]; }
-        // the odd pairs only live during the column pass (keeps the register peak down)
-        v2f wq[NP - 1];
-#pragma unroll
-        for (int t = 0; t < NP - 1; ++t) { wq[t].x = wp[t].y; wq[t].y = wp[t + 1].x; }
         if (ii + G < i1) issue_rows(ii + G + R);
         if (NBUF == 1) __syncthreads();
 #pragma unroll
         for (int g = 0; g < G; g += 2) {
-            const v2f ctr = SA_WPAIR(g + R);
+            const v2f ctr = win_pair(wp, g + R);
             v2f s = ctr * tp.g[0];
 #pragma unroll
             for (int k = 1; k <= R; ++k)
-                s = s + tp.g[k] * (SA_WPAIR(g + R - k) + SA_WPAIR(g + R + k));
+                s = s + tp.g[k] * win_pair_sum(wp, g + R - k, g + R + k);
             l_tmp[buf][g][tid] = s.x;
             l_tmp[buf][g + 1][tid] = s.y;
             if (dog || flags) {          // unfiltered centre samples, for the DoG epilogue
@@ -489,22 +503,22 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             const int hg = item / NG, hq = item - hg * NG;
             const int row = ii + hg, xo = x0 + 4 * hq;
             if (item < ITEMS && row < i1 && xo < w) {
-                float hw[4 + 2 * RP];
+                // window as aligned pairs hp[i] = {row[2i], row[2i+1]}
+                v2f hp[(4 + 2 * RP) / 2];
                 const float* lrow = &l_tmp[buf][hg][4 * hq];
 #pragma unroll
                 for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
                     const v4f v = ld4(lrow + 4 * q);
-                    hw[4 * q + 0] = v.x; hw[4 * q + 1] = v.y; hw[4 * q + 2] = v.z; hw[4 * q + 3] = v.w;
+                    hp[2 * q] = v2f{v.x, v.y};
+                    hp[2 * q + 1] = v2f{v.z, v.w};
                 }
-                float o4[4];
+                v2f o01 = hp[RP / 2] * tp.g[0], o23 = hp[RP / 2 + 1] * tp.g[0];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float s = __fmul_rn(hw[RP + q], tp.g[0].x);
-#pragma unroll
-                    for (int k = 1; k <= R; ++k)
-                        s = __fadd_rn(s, __fmul_rn(tp.g[k].x, __fadd_rn(hw[RP + q - k], hw[RP + q + k])));
-                    o4[q] = s;
+                for (int k = 1; k <= R; ++k) {
+                    o01 = o01 + tp.g[k] * win_pair_sum(hp, RP - k, RP + k);
+                    o23 = o23 + tp.g[k] * win_pair_sum(hp, RP + 2 - k, RP + 2 + k);
                 }
+                const float o4[4] = {o01.x, o01.y, o23.x, o23.y};
                 const bool vec = VW || (vec_w && (xo + 4 <= w));
                 const long long off = (long long)row * w + xo;
                 if (out) {
@@ -554,7 +568,6 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
     }
-#undef SA_WPAIR
 }
 
 // Any radius (taps in global memory); one thread per output sample.  Only used for
