@@ -247,6 +247,12 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     }
     if (!(p->delta_min <= 1.f) || !(p->delta_min > 0.f)) { sa_set_error("delta_min must be in (0,1]"); return nullptr; }
     if (!(L->sigmas[0][0] >= sigma_in)) { sa_set_error("sigma_min must be >= sigma_in"); return nullptr; }
+    // the blur kernels address one image with 32-bit byte offsets
+    if ((long long)L->w[0] * L->h[0] * 4 >= (1ll << 31) || (long long)im_w * im_h * 4 >= (1ll << 31)) {
+        sa_set_error("image too large: %dx%d (first octave %dx%d) exceeds 2 GiB per scale-space image",
+                     im_w, im_h, L->w[0], L->h[0]);
+        return nullptr;
+    }
     if (hipSetDevice(device) != hipSuccess) { sa_set_error("hipSetDevice(%d) failed", device); return nullptr; }
 
     sift_amd_ctx* c = new sift_amd_ctx();

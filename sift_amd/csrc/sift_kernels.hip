@@ -28,6 +28,33 @@ __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d
     *reinterpret_cast<v4f*>(__builtin_assume_aligned(p, 16)) = v;
 }
 
+// Buffer addressing for the fused blur: a wave-uniform resource (base of one image) and a
+// wave-uniform byte offset (row) live in scalar registers, the lane supplies a 32-bit byte
+// offset, so an access costs no vector address arithmetic.  Images are below 2 GiB
+// (checked when a context is created).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, row_bytes, 0));
+}
+__device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_bytes, row_bytes, 0);
+}
+__device__ __forceinline__ void buf_st2(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes, v2f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, lane_bytes, row_bytes, 0);
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes, v4f v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, lane_bytes, row_bytes, 0);
+}
+
 #define SA_PI 3.14159265358979323846
 #define SA_SQRT2 1.41421356237309504880
 
@@ -292,7 +319,7 @@ k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
 // Source sample (i, col) of the fused blur when the source is the bilinearly oversampled
 // input (OVS): same expression and operation order as k_oversample / lib_discrete.c:207-237.
 struct OvsCol { int jm, jp; float fy; };
-__device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int wi, int hi, float delta,
+__device__ __forceinline__ float ovs_sample(__amdgpu_buffer_rsrc_t img, int wi, int hi, float delta,
                                             int i, const OvsCol& c)
 {
     const float x = i * delta;
@@ -300,8 +327,9 @@ __device__ __forceinline__ float ovs_sample(const float* __restrict__ img, int w
     if (ip >= hi) ip = 2 * hi - 1 - ip;
     if (im >= hi) im = 2 * hi - 1 - im;
     const float fx = x - floorf(x);
-    const float a = img[(long long)ip * wi + c.jp], b = img[(long long)ip * wi + c.jm];
-    const float cc = img[(long long)im * wi + c.jp], d = img[(long long)im * wi + c.jm];
+    const unsigned rp = (unsigned)(ip * wi) * 4u, rm = (unsigned)(im * wi) * 4u;
+    const float a = buf_ld(img, c.jp * 4u, rp), b = buf_ld(img, c.jm * 4u, rp);
+    const float cc = buf_ld(img, c.jp * 4u, rm), d = buf_ld(img, c.jm * 4u, rm);
     const float top = __fadd_rn(__fmul_rn(c.fy, a), __fmul_rn(1 - c.fy, b));
     const float bot = __fadd_rn(__fmul_rn(c.fy, cc), __fmul_rn(1 - c.fy, d));
     return __fadd_rn(__fmul_rn(fx, top), __fmul_rn(1 - fx, bot));
@@ -351,7 +379,13 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const long long b = vid / (nbx * nby);
     const int x0 = bx * TW;
     const int col = mirror_idx(x0 - RP + tid, w);
-    const float* src = in + b * s_in + (OVS ? 0 : col);
+    const __amdgpu_buffer_rsrc_t src = buf_rsrc(in + b * s_in);
+    const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(out ? out + b * s_out : nullptr);
+    const __amdgpu_buffer_rsrc_t r_dog = buf_rsrc(dog ? dog + b * s_dog : nullptr);
+    const __amdgpu_buffer_rsrc_t r_sub = buf_rsrc(sub ? sub + b * s_sub : nullptr);
+    const __amdgpu_buffer_rsrc_t r_flags =
+        buf_rsrc(flags ? flags + b * ((h + 7) >> 3) * (long long)((w + 63) >> 6) : nullptr);
+    const unsigned ucol = (unsigned)col * 4u;
     OvsCol oc;
     if (OVS) {
         const float y = col * delta;
@@ -363,7 +397,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     auto load = [&](int i) -> float {
         const int r = mirror_idx(i, h);
         if (OVS) return ovs_sample(src, wi, hi, delta, r, oc);
-        return src[(long long)r * w];
+        return buf_ld(src, ucol, (unsigned)(r * w) * 4u);
     };
     const int i0 = by * strip;
     const int i1 = min(i0 + strip, h);
@@ -394,7 +428,8 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             for (int t = 0; t < G / 2 + 2; ++t) {
                 H[t] = 0.f;
                 if (t < G / 2 + 1 || odd) {
-                    const float a = src[(long long)(m + t) * wi + oc.jp], b = src[(long long)(m + t) * wi + oc.jm];
+                    const unsigned rp = (unsigned)((m + t) * wi) * 4u;
+                    const float a = buf_ld(src, oc.jp * 4u, rp), b = buf_ld(src, oc.jm * 4u, rp);
                     H[t] = __fadd_rn(__fmul_rn(oc.fy, a), __fmul_rn(1 - oc.fy, b));
                 }
             }
@@ -440,8 +475,9 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             for (int t = 0; t < G / 2 + 2; ++t) {
                 // the last row is only needed for an odd start; reading row m+t <= hi-1 is always in range
                 const int row = min(m + t, hi - 1);
-                raw[2 * t] = src[(long long)row * wi + oc.jp];
-                raw[2 * t + 1] = src[(long long)row * wi + oc.jm];
+                const unsigned rp = (unsigned)(row * wi) * 4u;
+                raw[2 * t] = buf_ld(src, oc.jp * 4u, rp);
+                raw[2 * t + 1] = buf_ld(src, oc.jm * 4u, rp);
             }
             raw_pending = true;
         } else {
@@ -520,15 +556,17 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 }
                 const float o4[4] = {o01.x, o01.y, o23.x, o23.y};
                 const bool vec = VW || (vec_w && (xo + 4 <= w));
-                const long long off = (long long)row * w + xo;
+                // store addresses: wave-uniform byte offset of the first row of this iteration plus
+                // a lane offset that does not change from iteration to iteration
+                const unsigned tile_off = (unsigned)(ii * w) * 4u;
+                const unsigned loff = (unsigned)(hg * w + xo) * 4u;
                 if (out) {
-                    float* po = out + b * s_out + off;
                     if (vec) {
-                        st4(po, o4[0], o4[1], o4[2], o4[3]);
+                        buf_st4(r_out, loff, tile_off, v4f{o4[0], o4[1], o4[2], o4[3]});
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (xo + q < w) po[q] = o4[q];
+                            if (xo + q < w) buf_st1(r_out, loff + 4 * q, tile_off, o4[q]);
                     }
                 }
                 if (dog || flags) {
@@ -536,31 +574,31 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                     const float d4[4] = {__fsub_rn(o4[0], pv.x), __fsub_rn(o4[1], pv.y),
                                          __fsub_rn(o4[2], pv.z), __fsub_rn(o4[3], pv.w)};
                     if (dog) {
-                        float* pd = dog + b * s_dog + off;
                         if (vec) {
-                            st4(pd, d4[0], d4[1], d4[2], d4[3]);
+                            buf_st4(r_dog, loff, tile_off, v4f{d4[0], d4[1], d4[2], d4[3]});
                         } else {
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
-                                if (xo + q < w) pd[q] = d4[q];
+                                if (xo + q < w) buf_st1(r_dog, loff + 4 * q, tile_off, d4[q]);
                         }
                     }
                     // mark the 8-row x 64-column cell if a sample passes the first contrast test
                     // (columns past w hold mirrored data and only ever add marks)
                     if (flags) {
                         const float m = fmaxf(fmaxf(fabsf(d4[0]), fabsf(d4[1])), fmaxf(fabsf(d4[2]), fabsf(d4[3])));
-                        if (m > flag_thr)
-                            flags[(b * ((h + 7) >> 3) + (row >> 3)) * (long long)((w + 63) >> 6) + (xo >> 6)] = 1;
+                        if (m > flag_thr)      // strips start at multiples of 8 rows: row >> 3 is uniform
+                            __builtin_amdgcn_raw_buffer_store_b32(1u, r_flags, (unsigned)(xo >> 6) * 4u,
+                                                                  (unsigned)((ii >> 3) * ((w + 63) >> 6)) * 4u, 0);
                     }
                 }
-                if (sub && !(row & 1) && (row >> 1) < ho) {
-                    float* ps = sub + b * s_sub + (long long)(row >> 1) * wo + (xo >> 1);
+                if (sub && !(hg & 1) && (row >> 1) < ho) {
+                    const unsigned soff = (unsigned)((hg >> 1) * wo + (xo >> 1)) * 4u;
+                    const unsigned srow = (unsigned)((ii >> 1) * wo) * 4u;
                     if (VW || (((wo & 1) == 0) && (xo >> 1) + 2 <= wo)) {
-                        v2f v = {o4[0], o4[2]};
-                        *reinterpret_cast<v2f*>(__builtin_assume_aligned(ps, 8)) = v;
+                        buf_st2(r_sub, soff, srow, v2f{o4[0], o4[2]});
                     } else {
-                        if ((xo >> 1) < wo) ps[0] = o4[0];
-                        if ((xo >> 1) + 1 < wo) ps[1] = o4[2];
+                        if ((xo >> 1) < wo) buf_st1(r_sub, soff, srow, o4[0]);
+                        if ((xo >> 1) + 1 < wo) buf_st1(r_sub, soff + 4, srow, o4[2]);
                     }
                 }
             }
@@ -1786,7 +1824,7 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     int strip = EW == 512 ? 128 : 64;
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
-    if (forced > 0) strip = forced;
+    if (forced > 0) strip = (forced + 7) & ~7;     // the kernel relies on strips of whole 8-row groups
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
     float* out = a.out;
     SaTapPairs tp2;
@@ -1954,7 +1992,9 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
     static const bool block_form = getenv("SIFT_AMD_DESCR") && !strcmp(getenv("SIFT_AMD_DESCR"), "block");
     const int nd = sc.n_hist * sc.n_hist * sc.n_ori;
     if (!block_form) {
-        const dim3 grid(4096, batch), blk(64);
+        // one wave per keypoint, further keypoints of an image in a grid-stride loop; most images
+        // have fewer keypoints than this and empty blocks are not free to dispatch
+        const dim3 grid(1024, batch), blk(64);
         switch ((nd + 63) / 64) {
             case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
             case 2: {

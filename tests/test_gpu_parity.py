@@ -189,3 +189,11 @@ def test_unsupported_parameters_are_refused_with_a_message(hip, kw, needle):
 def test_image_too_small_for_one_octave_is_refused(hip):
     with pytest.raises(sift_amd.api.SiftAmdError):
         sift_amd.Context(4, 4)
+
+
+def test_image_beyond_32_bit_offsets_is_refused(hip):
+    """One scale-space image must stay below 2 GiB (the blur addresses it with 32-bit byte
+    offsets); the refusal comes before any allocation."""
+    with pytest.raises(sift_amd.api.SiftAmdError) as e:
+        sift_amd.Context(20000, 14000)
+    assert "too large" in str(e.value)
