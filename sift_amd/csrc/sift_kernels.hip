@@ -92,6 +92,26 @@ __device__ __forceinline__ float lane_next(float v)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
+// 64-bit value of lane i-1 (lane 0 receives 0)
+__device__ __forceinline__ unsigned long long lane_prev_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, 0x138, 0xf, 0xf, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// Inclusive prefix sum over the 64 lanes of a fully active wave: shifts inside the rows of 16
+// lanes, then the row totals are passed on (row_bcast15 to rows 1 and 3, row_bcast31 to rows 2, 3).
+__device__ __forceinline__ int wave_scan_inclusive(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(fminf(a, b), c); }
 
@@ -1403,15 +1423,31 @@ __device__ __forceinline__ float seq_l2norm(const float* d, int n)
     return (float)sqrt((double)l2);
 }
 
+#ifdef SA_DESCR_PROF
+__device__ unsigned long long sa_prof[16];
+extern "C" void sift_amd_debug_prof(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_prof), sizeof(sa_prof));
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(sa_prof), z, sizeof(z)); }
+}
+#define PROF_T(k) { const long long t_ = clock64(); pacc[k] += t_ - tprof; tprof = clock64(); }
+#else
+#define PROF_T(k)
+#endif
 template <int BPL>
 __device__ __forceinline__ void
 descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
                      int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
 {
     constexpr int POOL = 256;
-    // one slot of slack: the list walk reads one entry ahead
-    __shared__ __attribute__((aligned(16))) double p_c[POOL + 1][2];   // contribution to bin k0 / k0+1
-    __shared__ int p_k[POOL + 1];
+    // Contribution pool, used in one of two ways.  Per-bin lists: up to 512 contributions, every
+    // list padded to an even length (64*BPL more slots), plus slack because the walk reads one
+    // pair ahead.  Per-cell lists: POOL+1 entries of two contributions (bins k0 / k0+1) and the
+    // orientation bin k0 of each.
+    constexpr int POOL_LISTS = (512 + 64 * BPL + 4) * 8, POOL_CELLS = (POOL + 1) * 16 + (POOL + 1) * 4 + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char pool_raw[POOL_LISTS > POOL_CELLS ? POOL_LISTS : POOL_CELLS];
+    double (*p_c)[2] = reinterpret_cast<double(*)[2]>(pool_raw);
+    int* p_k = reinterpret_cast<int*>(pool_raw + (POOL + 1) * 16);
     __shared__ int q_pix[128];
     __shared__ int cstart[SA_MAX_CELLS + 1];
     // per-bin lists (n_ori <= 64): list starts, and per batch the lane mask of every cell and
@@ -1438,8 +1474,12 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     // One list per descriptor bin instead of one per cell: a lane then touches only the
     // contributions of its own bins.  Needs a lane per orientation bin for the bookkeeping.
     const bool bin_lists = Nb <= 64 && !(sc.debug & 2);
-    double* pool = &p_c[0][0];                 // 2*(POOL+1) doubles: up to 512 contributions + slack
+    double* pool = reinterpret_cast<double*>(pool_raw);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
+#ifdef SA_DESCR_PROF
+        long long pacc[12] = {0};
+        long long tprof = clock64();
+#endif
         const SaKey key = keys[b * kcap + q];
         const SaOctave& oc = P.oct[key.o];
         const int w = oc.w, h = oc.h;
@@ -1470,6 +1510,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
         // positions per round without divisions
         int fi = 0, fj = 0;
         if (npix > 0) { fi = lane / nw; fj = lane - fi * nw; }
+        PROF_T(0)
         while (p0 < npix || qn > 0) {
             // ---- queue the samples inside the rotated window, in raster order
             while (qn < 64 && p0 < npix) {
@@ -1488,6 +1529,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 while (fj >= nw) { fj -= nw; ++fi; }
             }
             __syncthreads();
+            PROF_T(1)
             const int nproc = min(qn, 64);
             const bool act = lane < nproc;
             // ---- geometry of my sample, cell ranks
@@ -1504,6 +1546,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 a0 = (int)floor((double)al);
                 b0 = (int)floor((double)be);
             }
+            PROF_T(2)
             if (bin_lists) {
                 // ---- my sample's orientation bin pair, weights and magnitude
                 int k0 = 0, k1 = 0;
@@ -1522,6 +1565,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     wl = 1. - ((double)ga - gf);
                     wr = 1.0 - (gf + 1 - (double)ga);
                 }
+                PROF_T(3)
                 // ---- kk_s[k]: lanes whose sample adds to orientation bin k (its own bin k0 == k,
                 // or k0 == k-1 through the second weight); lane k collects the mask of k0 == k
                 unsigned long long myK = 0;
@@ -1530,11 +1574,15 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     if (lane == k) myK = m;
                 }
                 {
-                    const int src = lane == 0 ? Nb - 1 : lane - 1;
-                    const unsigned lo = __shfl((unsigned)myK, src), hi = __shfl((unsigned)(myK >> 32), src);
-                    if (lane < Nb) kk_s[lane] = myK | (((unsigned long long)hi << 32) | lo);
+                    // mask of the bin before mine (bin Nb-1 for bin 0)
+                    unsigned long long prevK = lane_prev_u64(myK);
+                    const unsigned lastLo = __builtin_amdgcn_readlane((int)(unsigned)myK, Nb - 1);
+                    const unsigned lastHi = __builtin_amdgcn_readlane((int)(unsigned)(myK >> 32), Nb - 1);
+                    if (lane == 0) prevK = ((unsigned long long)lastHi << 32) | lastLo;
+                    if (lane < Nb) kk_s[lane] = myK | prevK;
                 }
                 __syncthreads();
+                PROF_T(4)
                 unsigned long long mA = 0, mB = 0;
                 if (act) { mA = kk_s[k0]; mB = kk_s[k1]; }
                 // ---- which samples touch which cell: a sample with corner (a0, b0) touches the cell
@@ -1547,12 +1595,11 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                         const unsigned long long ma_ = __ballot(act && a0 == a), mb_ = __ballot(act && b0 == a);
                         if (lane == a + 1) { tA = ma_; tB = mb_; }
                     }
-                    const int src = lane == 0 ? 63 : lane - 1;     // lane 63 holds 0 (Nh <= 8)
-                    const unsigned long long pA = ((unsigned long long)__shfl((unsigned)(tA >> 32), src) << 32) | __shfl((unsigned)tA, src);
-                    const unsigned long long pB = ((unsigned long long)__shfl((unsigned)(tB >> 32), src) << 32) | __shfl((unsigned)tB, src);
+                    const unsigned long long pA = lane_prev_u64(tA), pB = lane_prev_u64(tB);
                     if (lane <= Nh + 1) { pa_s[lane] = tA | pA; pb_s[lane] = tB | pB; }
                 }
                 __syncthreads();
+                PROF_T(5)
                 // ranks of my two contributions inside every cell I touch (8 bits per slot)
                 int rankL = 0, rankR = 0;
                 if (act) {
@@ -1570,28 +1617,27 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     cm_s[lane] = pa_s[ci + 1] & pb_s[cj + 1];
                 }
                 __syncthreads();
+                PROF_T(6)
                 // ---- list length of my bins, list starts by a scan in bin order
                 int cnt[BPL], start[BPL], tot = 0;
 #pragma unroll
                 for (int u = 0; u < BPL; ++u) {
                     cnt[u] = my_cell[u] >= 0 ? __popcll(cm_s[my_cell[u]] & kk_s[my_k[u]]) : 0;
                     start[u] = tot;
-                    tot += cnt[u];
+                    tot += (cnt[u] + 1) & ~1;      // lists start at even slots
                 }
                 {
-                    int inc = tot;
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const int t = __shfl_up(inc, d);
-                        if (lane >= d) inc += t;
-                    }
-                    const int excl = inc - tot;
+                    const int excl = wave_scan_inclusive(tot) - tot;
 #pragma unroll
                     for (int u = 0; u < BPL; ++u) {
                         start[u] += excl;
                         if (my_cell[u] >= 0) bstart_s[lane * BPL + u] = start[u];
+                        // odd lists end with +0.0, which leaves the non-negative accumulator as it is
+                        if (cnt[u] & 1) pool[start[u] + cnt[u]] = 0.0;
                     }
                 }
                 __syncthreads();
+                PROF_T(7)
                 // ---- my contributions go to their places in the lists
                 if (act) {
 #pragma unroll
@@ -1608,17 +1654,20 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     }
                 }
                 __syncthreads();
+                PROF_T(8)
                 // ---- every lane adds the lists of its bins, in order, next value loaded ahead
+                // (two entries per 16-byte read)
 #pragma unroll
                 for (int u = 0; u < BPL; ++u) {
-                    int e = start[u];
-                    const int e1 = e + cnt[u];
-                    double v = pool[e];
-                    while (e < e1) {
-                        const double nv = pool[e + 1];
-                        acc[u] = (float)((double)acc[u] + v);
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    const v2d* pl = reinterpret_cast<const v2d*>(pool) + (start[u] >> 1);
+                    const int np = (cnt[u] + 1) >> 1;
+                    v2d v = pl[0];
+                    for (int e = 0; e < np; ++e) {
+                        const v2d nv = pl[e + 1];
+                        acc[u] = (float)((double)acc[u] + v.x);
+                        acc[u] = (float)((double)acc[u] + v.y);
                         v = nv;
-                        ++e;
                     }
                 }
             } else {
@@ -1706,6 +1755,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     }
                 }
             }
+            PROF_T(9)
             // ---- pop the processed samples from the queue
             const int rem = qn - nproc;
             int moved = 0;
@@ -1714,6 +1764,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             if (lane < rem) q_pix[lane] = moved;
             qn = rem;
             __syncthreads();
+            PROF_T(10)
         }
 #pragma unroll
         for (int u = 0; u < BPL; ++u)
@@ -1746,6 +1797,15 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             o->x = key.x; o->y = key.y; o->scale = key.sigma; o->orientation = key.theta;
         }
         __syncthreads();
+        PROF_T(11)
+#ifdef SA_DESCR_PROF
+        if (threadIdx.x < 12) {
+            long long v = 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) if (threadIdx.x == k) v = pacc[k];
+            atomicAdd(&sa_prof[threadIdx.x], (unsigned long long)v);
+        }
+#endif
     }
 }
 

@@ -20,5 +20,17 @@ bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc k_blur_fused > $OUT/pmc_blur.txt
 python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)) 64 $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
 [ -s $OUT/traffic.json ] && cp $OUT/traffic.json $ROOT/profiles/traffic.json   # the bench line quotes it
+bash tools/pmc_one.sh $TAG/grbm GRBM_GUI_ACTIVE > $OUT/grbm.log 2>&1
+python3 tools/clock_from_pmc.py $OUT/grbm > $OUT/clock_per_kernel.md
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+# secondary measurements: keypoint-rich input, host-resident input, one batch at a time
+timeout -k 10 300 python3 bench.py --no-cpu --kind white > $OUT/bench_white.json 2>> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --no-cpu --host-input > $OUT/bench_host_input.json 2>> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --no-cpu --pipeline 1 > $OUT/bench_pipeline1.json 2>> $OUT/bench.err
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 64 --roofline > $OUT/per_kernel_roofline_b64.md 2>&1
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 > $OUT/per_kernel_single_1080p.md 2>&1
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 --w 3840 --h 2160 > $OUT/per_kernel_single_4k.md 2>&1
+# what the hardware gives: copy ceiling of HBM, issue rate of packed against plain f32 instructions
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/copy_bw tools/micro/copy_bw.hip && timeout -k 10 120 /tmp/copy_bw > $OUT/micro_copy_bw.txt
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/valu_rate tools/micro/valu_rate.hip && timeout -k 10 120 /tmp/valu_rate > $OUT/micro_valu_rate.txt
 echo done
