@@ -1130,11 +1130,12 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
                 if (ori < 0) ori = (float)((double)ori + 2 * SA_PI);
                 bin = (int)((double)ori / (2 * SA_PI) * nbins + 0.5) % nbins;
             }
-            const int lim = min(64, npix - p0);
-#pragma unroll 8
-            for (int e = 0; e < lim; ++e) {
-                const int be = __shfl(bin, e);
-                const float Me = __shfl(M, e);
+            // sample e's bin and magnitude reach the bin owners through scalar registers
+            // (v_readlane, no LDS traffic); lanes past the end of the patch hold bin -1
+#pragma unroll
+            for (int e = 0; e < 64; ++e) {
+                const int be = __builtin_amdgcn_readlane(bin, e);
+                const float Me = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(M), e));
                 if (be == lane) hb = __fadd_rn(hb, Me);
             }
         }
