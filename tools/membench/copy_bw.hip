@@ -1,6 +1,6 @@
 // Practical HBM ceiling for a read-one-write-one stream on this GPU: a grid-stride copy with
 // 16-byte accesses over buffers far larger than the caches, timed with events.
-//   hipcc --offload-arch=gfx950 -O2 -o copy_bw tools/micro/copy_bw.hip && ./copy_bw
+//   hipcc --offload-arch=gfx950 -O2 -o copy_bw tools/membench/copy_bw.hip && ./copy_bw
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

@@ -1,7 +1,7 @@
 // Relative issue rate of a few VALU instructions on gfx950: every wave runs a long unrolled
 // sequence of one instruction on independent registers; the time per instruction relative to
 // v_mov_b32 tells whether the packed / 64-bit forms are full rate.
-//   hipcc --offload-arch=gfx950 -O2 -o valu_rate tools/micro/valu_rate.hip && ./valu_rate
+//   hipcc --offload-arch=gfx950 -O2 -o valu_rate tools/membench/valu_rate.hip && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 

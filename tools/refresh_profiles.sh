@@ -31,6 +31,6 @@ timeout -k 10 200 python3 tools/kernel_bench.py --batch 64 --roofline > $OUT/per
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 > $OUT/per_kernel_single_1080p.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 --w 3840 --h 2160 > $OUT/per_kernel_single_4k.md 2>&1
 # what the hardware gives: copy ceiling of HBM, issue rate of packed against plain f32 instructions
-hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/copy_bw tools/micro/copy_bw.hip && timeout -k 10 120 /tmp/copy_bw > $OUT/micro_copy_bw.txt
-hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/valu_rate tools/micro/valu_rate.hip && timeout -k 10 120 /tmp/valu_rate > $OUT/micro_valu_rate.txt
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/copy_bw tools/membench/copy_bw.hip && timeout -k 10 120 /tmp/copy_bw > $OUT/micro_copy_bw.txt
+hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/valu_rate tools/membench/valu_rate.hip && timeout -k 10 120 /tmp/valu_rate > $OUT/micro_valu_rate.txt
 echo done
