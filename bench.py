@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--host-input", action="store_true",
                     help="diagnostic: images start in pinned host memory and are copied to the GPU "
                          "inside the timed region (PCIe-inclusive rate; not the headline value)")
-    ap.add_argument("--pipeline", type=int, default=3,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="contexts/streams used alternately (1 = strictly one batch at a time)")
     args = ap.parse_args()
 
@@ -125,9 +125,9 @@ def main():
     host = np.stack([synth.make(args.kind, W_IM, H_IM, seed=12345 + rank * B + b) for b in range(B)])
     d_imgs = torch.from_numpy(host).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    # Two contexts (two pyramid pools) on two streams, used alternately: the latency-bound tail of
-    # one batch (orientation, descriptors, host gather) overlaps the bandwidth-bound scale-space of
-    # the next.  Both batches read the same resident input images.
+    # Several contexts (one pyramid pool each) on their own streams, used in turn: the latency-bound
+    # tail of one batch (orientation, descriptors, host gather) overlaps the bandwidth-bound
+    # scale-space of the next.  All batches read the same resident input images.
     n_ctx = max(1, args.pipeline)
     ctxs = [sift_amd.Context(W_IM, H_IM, max_batch=B, device=local_rank) for _ in range(n_ctx)]
     streams = [torch.cuda.Stream() for _ in range(n_ctx)]
