@@ -1907,11 +1907,14 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
 template <int R>
 static void blur_fused_t(hipStream_t st, const BlurArgs& a)
 {
-    // wide tiles (480 outputs of 512 columns, 8 waves) halve the relative column halo and the idle
-    // row-pass slots: worth ~5 % where the arithmetic co-limits and the image is wide enough to
-    // keep all CUs busy (octave 0 of a 1080p image and up)
-    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 3000;
-    if (a.w >= wide_min) blur_fused_launch<R, 512, 2>(st, a);
+    // Tiles of 480 outputs (512 columns with the halo, 8 waves) or 224 outputs (256 columns,
+    // 4 waves): whichever covers the image width with fewer columns in total.  The wide tile has
+    // the smaller halo share and fewer idle row-pass slots (~5 % on octave 0 of a 1080p image) but
+    // wastes most of a tile on narrow octaves.  SIFT_AMD_WIDE_MIN=<width> forces the choice by width.
+    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 0;
+    const bool wide = wide_min > 0 ? a.w >= wide_min
+                                   : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
+    if (wide) blur_fused_launch<R, 512, 2>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }
 
