@@ -1451,10 +1451,10 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     int* p_k = reinterpret_cast<int*>(pool_raw + (POOL + 1) * 16);
     __shared__ int q_pix[128];
     __shared__ int cstart[SA_MAX_CELLS + 1];
-    // per-bin lists (n_ori <= 64): list starts, and per batch the lane mask of every cell and
-    // of every orientation-bin pair
+    // per-bin lists (n_ori <= 64): list starts, and per batch the lane masks of every pair of
+    // adjacent orientation bins, cell rows and cell columns
     __shared__ int bstart_s[SA_MAX_DESCR];
-    __shared__ unsigned long long cm_s[SA_MAX_CELLS], kk_s[64], pa_s[16], pb_s[16];
+    __shared__ unsigned long long kk_s[64], pa_s[16], pb_s[16];
     __shared__ __attribute__((aligned(16))) float d_s[SA_MAX_DESCR];
     __shared__ float norm_s;
     const int lane = threadIdx.x;
@@ -1462,11 +1462,13 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
     const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
     const unsigned long long lt = lanemask_lt();
-    int my_cell[BPL], my_k[BPL], my_kprev[BPL];
+    int my_cell[BPL], my_ci[BPL], my_cj[BPL], my_k[BPL], my_kprev[BPL];
 #pragma unroll
     for (int u = 0; u < BPL; ++u) {
         const int t = lane * BPL + u;
         my_cell[u] = t < nd ? t / Nb : -1;
+        my_ci[u] = t < nd ? my_cell[u] / Nh : 0;
+        my_cj[u] = t < nd ? my_cell[u] - my_ci[u] * Nh : 0;
         my_k[u] = t % Nb;
         my_kprev[u] = my_k[u] == 0 ? Nb - 1 : my_k[u] - 1;
     }
@@ -1506,7 +1508,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
 #pragma unroll
         for (int u = 0; u < BPL; ++u) acc[u] = 0.f;
 
-        int qn = 0, p0 = 0;
+        int qn = 0, p0 = 0, qhead = 0;     // q_pix is a ring of 128 entries
         // (row, column) inside the bounding box of raster position p0 + lane, advanced by 64
         // positions per round without divisions
         int fi = 0, fj = 0;
@@ -1523,7 +1525,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     in_win = fmaxf(fabsf(X), fabsf(Y)) < R;
                 }
                 const unsigned long long m = __ballot(in_win);
-                if (in_win) q_pix[qn + __popcll(m & lt)] = (fi << 16) | fj;
+                if (in_win) q_pix[(qhead + qn + __popcll(m & lt)) & 127] = (fi << 16) | fj;
                 qn += __popcll(m);
                 p0 += 64;
                 fj += 64;
@@ -1537,7 +1539,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             int si = 0, sj = 0, a0 = 0, b0 = 0;
             float X = 0.f, Y = 0.f, al = 0.f, be = 0.f;
             if (act) {
-                const int p = q_pix[lane];
+                const int p = q_pix[(qhead + lane) & 127];
                 si = i0 + (p >> 16); sj = j0 + (p & 0xffff);
                 const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
                 X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
@@ -1582,10 +1584,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     if (lane == 0) prevK = ((unsigned long long)lastHi << 32) | lastLo;
                     if (lane < Nb) kk_s[lane] = myK | prevK;
                 }
-                __syncthreads();
                 PROF_T(4)
-                unsigned long long mA = 0, mB = 0;
-                if (act) { mA = kk_s[k0]; mB = kk_s[k1]; }
                 // ---- which samples touch which cell: a sample with corner (a0, b0) touches the cell
                 // rows a0, a0+1 and columns b0, b0+1, so the mask of cell (ci, cj) is
                 // (samples with a0 in {ci-1, ci}) & (samples with b0 in {cj-1, cj}).  Lane p collects
@@ -1604,6 +1603,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 // ranks of my two contributions inside every cell I touch (8 bits per slot)
                 int rankL = 0, rankR = 0;
                 if (act) {
+                    const unsigned long long mA = kk_s[k0], mB = kk_s[k1];
                     const unsigned long long ra0 = pa_s[a0 + 1], ra1 = pa_s[a0 + 2];
                     const unsigned long long rb0 = pb_s[b0 + 1], rb1 = pb_s[b0 + 2];
 #pragma unroll
@@ -1613,17 +1613,12 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                         rankR |= __popcll(m & mB) << (8 * sl);
                     }
                 }
-                if (lane < ncell) {
-                    const int ci = lane / Nh, cj = lane - ci * Nh;
-                    cm_s[lane] = pa_s[ci + 1] & pb_s[cj + 1];
-                }
-                __syncthreads();
                 PROF_T(6)
                 // ---- list length of my bins, list starts by a scan in bin order
                 int cnt[BPL], start[BPL], tot = 0;
 #pragma unroll
                 for (int u = 0; u < BPL; ++u) {
-                    cnt[u] = my_cell[u] >= 0 ? __popcll(cm_s[my_cell[u]] & kk_s[my_k[u]]) : 0;
+                    cnt[u] = my_cell[u] >= 0 ? __popcll(pa_s[my_ci[u] + 1] & pb_s[my_cj[u] + 1] & kk_s[my_k[u]]) : 0;
                     start[u] = tot;
                     tot += (cnt[u] + 1) & ~1;      // lists start at even slots
                 }
@@ -1758,12 +1753,8 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             }
             PROF_T(9)
             // ---- pop the processed samples from the queue
-            const int rem = qn - nproc;
-            int moved = 0;
-            if (lane < rem) moved = q_pix[nproc + lane];
-            __syncthreads();
-            if (lane < rem) q_pix[lane] = moved;
-            qn = rem;
+            qhead = (qhead + nproc) & 127;
+            qn -= nproc;
             __syncthreads();
             PROF_T(10)
         }
