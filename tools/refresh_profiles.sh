@@ -5,8 +5,10 @@ set -e
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-# octave-0 blur launch of 64 1080p images: 8 x 17 tiles of 480 x 128 outputs per image, 512 threads
-DOM_BLOCKS=8704
+# octave-0 blur launch of 128 1080p images (the bench's batch): 8 x 17 tiles of 480 x 128 outputs
+# per image, 512 threads
+BATCH=128
+DOM_BLOCKS=$((8 * 17 * BATCH))
 DOM_THREADS=512
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -18,7 +20,7 @@ python3 tools/trace_by_grid.py $OUT/stats "" 40 > $OUT/by_grid.txt
 python3 tools/dominant_from_trace.py $OUT/stats $DOM_BLOCKS 50 > $OUT/dominant_kernel_rocprof.txt
 bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc k_blur_fused > $OUT/pmc_blur.txt
-python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)) 64 $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
+python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)) $BATCH $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
 [ -s $OUT/traffic.json ] && cp $OUT/traffic.json $ROOT/profiles/traffic.json   # the bench line quotes it
 bash tools/pmc_one.sh $TAG/grbm GRBM_GUI_ACTIVE > $OUT/grbm.log 2>&1
 python3 tools/clock_from_pmc.py $OUT/grbm > $OUT/clock_per_kernel.md
