@@ -28,6 +28,7 @@ timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 # secondary measurements: keypoint-rich input, host-resident input, one batch at a time
 timeout -k 10 300 python3 bench.py --no-cpu --kind white > $OUT/bench_white.json 2>> $OUT/bench.err
 timeout -k 10 300 python3 bench.py --no-cpu --host-input > $OUT/bench_host_input.json 2>> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --no-cpu --host-input-u8 > $OUT/bench_host_input_u8.json 2>> $OUT/bench.err
 timeout -k 10 300 python3 bench.py --no-cpu --pipeline 1 > $OUT/bench_pipeline1.json 2>> $OUT/bench.err
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 64 --roofline > $OUT/per_kernel_roofline_b64.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 > $OUT/per_kernel_single_1080p.md 2>&1
