@@ -1873,7 +1873,7 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
     // sequentially, so small octaves get short strips to keep enough blocks in flight
     static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
-    int strip = EW == 512 ? 128 : 64;
+    int strip = EW == 512 ? (a.ovs_w > 0 ? 256 : 128) : 64;    // (the oversampling prologue is the costliest)
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (forced > 0) strip = (forced + 7) & ~7;     // the kernel relies on strips of whole 8-row groups
