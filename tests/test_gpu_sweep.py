@@ -1,6 +1,8 @@
-"""GPU: a short fixed-seed run of the randomised parity sweep (tests/sweep_parity.py)."""
+"""GPU: short fixed-seed runs of the randomised sweeps (tests/sweep_parity.py,
+tests/sweep_matching.py)."""
 import pytest
 
+import sweep_matching
 import sweep_parity
 
 pytestmark = pytest.mark.gpu
@@ -8,3 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_random_sizes_kinds_and_parameters_match_the_oracle(hip):
     assert sweep_parity.sweep(12, seed=2026, verbose=False) > 500
+
+
+def test_random_matching_cases_match_the_oracle(hip):
+    assert sweep_matching.sweep(25, seed=2026, verbose=False) > 100
