@@ -1435,7 +1435,9 @@ extern "C" void sift_amd_debug_prof(unsigned long long* out, int reset)
 #else
 #define PROF_T(k)
 #endif
-template <int BPL>
+// NH, NB: descriptor shape known at compile time (0 = taken from the parameters at run time);
+// the mask loops over cell rows/columns and orientation bins then unroll.
+template <int BPL, int NH = 0, int NB = 0>
 __device__ __forceinline__ void
 descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
                      int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
@@ -1460,7 +1462,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     const int lane = threadIdx.x;
     const long long b = blockIdx.y;
     const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
-    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
+    const int Nh = NH ? NH : sc.n_hist, Nb = NB ? NB : sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
     const unsigned long long lt = lanemask_lt();
     int my_cell[BPL], my_ci[BPL], my_cj[BPL], my_k[BPL], my_kprev[BPL];
 #pragma unroll
@@ -1476,7 +1478,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     const bool one_cell = (Nb % BPL) == 0 && !(sc.debug & 1);
     // One list per descriptor bin instead of one per cell: a lane then touches only the
     // contributions of its own bins.  Needs a lane per orientation bin for the bookkeeping.
-    const bool bin_lists = Nb <= 64 && !(sc.debug & 2);
+    const bool bin_lists = NB ? true : (Nb <= 64 && !(sc.debug & 2));   // (fixed shapes: launched without debug switches)
     double* pool = reinterpret_cast<double*>(pool_raw);
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
 #ifdef SA_DESCR_PROF
@@ -1821,6 +1823,14 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
 SA_DESCR_WPE(4)
 SA_DESCR_WPE(5)
 
+// The default 4 x 4 x 8 shape.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_descriptor_wave_448(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
+                      int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
+{
+    descriptor_wave_body<2, 4, 8>(P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+}
+
 // Output records of a batch, image after image without gaps, so that the host gather is one
 // copy.  Block (x, b) copies a slice of image b's records to its offset (sum of the counts of
 // the images before it); 144-byte records move as 36 dwords.
@@ -2054,7 +2064,9 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
             case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
             case 2: {
                 static const int wpe = getenv("SIFT_AMD_DESCR_WPE") ? atoi(getenv("SIFT_AMD_DESCR_WPE")) : 4;
-                if (wpe == 4) HIPK(k_descriptor_wave2_wpe4, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+                if (wpe == 4 && sc.n_hist == 4 && sc.n_ori == 8 && !sc.debug)
+                    HIPK(k_descriptor_wave_448, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+                else if (wpe == 4) HIPK(k_descriptor_wave2_wpe4, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
                 else if (wpe == 5) HIPK(k_descriptor_wave2_wpe5, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
                 else HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
                 break;
