@@ -1114,12 +1114,15 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
         const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
         const float denom = __fmul_rn(__fmul_rn(2.f, sc.lambda_ori), sc.lambda_ori);
         float hb = 0.f;
+        // (row, column) of raster position p0 + lane, advanced by 64 positions per chunk
+        int fi = 0, fj = 0;
+        if (npix > 0) { fi = lane / nw; fj = lane - fi * nw; }
         for (int p0 = 0; p0 < npix; p0 += 64) {
             const int p = p0 + lane;
             int bin = -1;
             float M = 0.f;
             if (p < npix) {
-                const int si = i0 + p / nw, sj = j0 + p % nw;
+                const int si = i0 + fi, sj = j0 + fj;
                 const float sX = __fdiv_rn(__fsub_rn((float)si, xk), sk);
                 const float sY = __fdiv_rn(__fsub_rn((float)sj, yk), sk);
                 const float dx = grad_i(im, w, h, si, sj);
@@ -1128,8 +1131,11 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
                 const float r2 = __fadd_rn(__fmul_rn(sX, sX), __fmul_rn(sY, sY));
                 M = (float)(hypot((double)dx, (double)dy) * exp((double)__fdiv_rn(-r2, denom)));
                 if (ori < 0) ori = (float)((double)ori + 2 * SA_PI);
-                bin = (int)((double)ori / (2 * SA_PI) * nbins + 0.5) % nbins;
+                bin = (int)((double)ori / (2 * SA_PI) * nbins + 0.5);
+                bin = (unsigned)bin < 2u * (unsigned)nbins ? (bin >= nbins ? bin - nbins : bin) : bin % nbins;
             }
+            fj += 64;
+            while (fj >= nw) { fj -= nw; ++fi; }
             // sample e's bin and magnitude reach the bin owners through scalar registers
             // (v_readlane, no LDS traffic); lanes past the end of the patch hold bin -1
 #pragma unroll
