@@ -211,3 +211,40 @@ def test_c_matching_host_program(hip, tmp_path):
         assert vals[0] == float("%f" % xy[0][i, 0]) and vals[1] == float("%f" % xy[0][i, 1])
         j = want["iA"][i]
         assert vals[4] == float("%f" % xy[1][j, 0]) and vals[5] == float("%f" % xy[1][j, 1])
+
+
+def test_concurrent_host_threads(hip):
+    """The reference is re-entrant (no globals); the replacement must be too: four host threads
+    call the reference-named sift_compute_features and a batched context of their own at the
+    same time, on different images, and get what a single thread gets."""
+    import threading
+    w, h, n_threads, rounds = 240, 180, 4, 3
+    imgs = [synth.make("white", w, h, seed=900 + t) for t in range(n_threads)]
+
+    def flat(img):
+        return api.sift_compute_features(img)
+
+    def batched(img):
+        with sift_amd.Context(w, h, max_batch=2) as ctx:
+            ctx.detect_host(np.stack([img, img]))
+            return ctx.keypoints(1)[0].tobytes()
+
+    want = [(flat(im).tobytes(), batched(im)) for im in imgs]
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(rounds):
+                assert flat(imgs[t]).tobytes() == want[t][0]
+                assert batched(imgs[t]) == want[t][1]
+            hip.sift_amd_release_thread_cache()
+        except BaseException as e:       # noqa: BLE001 - reported to the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(want[0][0]) > 144 * 20
