@@ -324,6 +324,11 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     cap = std::min<long long>(cap, 1 << 24);
     c->cap = (int)cap;
     c->fcap = (int)std::max<long long>(4096, cap / 4);
+    // SIFT_AMD_CAP=<n>: list capacities forced small, to exercise the overflow report
+    if (const char* m = getenv("SIFT_AMD_CAP")) {
+        c->cap = std::max(64, atoi(m));
+        c->fcap = std::max(16, c->cap / 4);
+    }
     c->kcap = 2 * c->fcap;
     if (dev_alloc(c, &c->d_ckey, (size_t)(B * c->cap))) return fail();
     if (dev_alloc(c, &c->d_cval, (size_t)(B * c->cap))) return fail();

@@ -197,3 +197,27 @@ def test_image_beyond_32_bit_offsets_is_refused(hip):
     with pytest.raises(sift_amd.api.SiftAmdError) as e:
         sift_amd.Context(20000, 14000)
     assert "too large" in str(e.value)
+
+
+def test_list_overflow_is_reported_not_silent(hip, monkeypatch):
+    """With the candidate/keypoint lists forced far too small, every kernel stays inside its
+    buffers and the run reports the overflow instead of returning a truncated result."""
+    w, h = 200, 150
+    img = synth.make("white", w, h, seed=31)
+    with sift_amd.Context(w, h) as ctx:
+        ctx.detect_host(img)
+        sizes, _ = ctx.stage_counts(0)
+    n_cand, n_final = int(sizes[1]), int(sizes[5])
+    assert n_cand > 64 and n_final > (n_cand + 8) // 4
+    # candidate list too small; then candidates fit but the survivor/key lists (a quarter) do not
+    for cap in (64, n_cand + 8):
+        monkeypatch.setenv("SIFT_AMD_CAP", str(cap))
+        with sift_amd.Context(w, h, max_batch=2) as ctx:
+            ctx.detect_host(np.stack([img, img]))
+            with pytest.raises(sift_amd.api.SiftAmdError) as e:
+                ctx.counts()
+            assert "overflow" in str(e.value)
+    monkeypatch.delenv("SIFT_AMD_CAP")
+    with sift_amd.Context(w, h) as ctx:      # and the library is fine afterwards
+        ctx.detect_host(img)
+        assert ctx.counts()[0] == len(pyoracle.run(img, keep_ss=False)["keys"]["ints"])
