@@ -221,3 +221,30 @@ def test_list_overflow_is_reported_not_silent(hip, monkeypatch):
     with sift_amd.Context(w, h) as ctx:      # and the library is fine afterwards
         ctx.detect_host(img)
         assert ctx.counts()[0] == len(pyoracle.run(img, keep_ss=False)["keys"]["ints"])
+
+
+@pytest.mark.parametrize("name,value", [("nan", np.nan), ("inf", np.inf), ("huge", 1e30), ("negative", -5.0),
+                                        ("denormal-range", None)])
+def test_unusual_sample_values(hip, name, value):
+    """Out-of-range, non-finite and denormal-range samples: the lists from the first contrast
+    test on and the final records equal the oracle's.  (The list of all discrete extrema is not
+    compared for NaN/Inf: the reference lists every NaN sample of the DoG stack there.)"""
+    w, h = 96, 80
+    img = synth.make("white", w, h, seed=5)
+    if value is None:
+        img = (img * np.float32(1e-38)).astype(np.float32)
+    else:
+        img[40, 48] = value
+    want = pyoracle.run(img, keep_ss=False)
+    with sift_amd.Context(w, h, keep_all_extrema=True) as ctx:
+        ctx.detect_host(img)
+        sizes, _ = ctx.stage_counts(0)
+        std, _ = ctx.keypoints(0)
+        _, descr, _ = ctx.extras(0)
+    first = 1 if name in ("nan", "inf") else 0
+    assert list(sizes[first:]) == [len(want["stages"][s]["ints"]) for s in "ABCDEF"[first:]]
+    assert len(std) == len(want["keys"]["ints"])
+    if len(std):
+        got = np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1)
+        assert same_bits(got, want["keys"]["flts"][:, :4])
+        assert np.array_equal(descr, want["keys"]["descr"])
