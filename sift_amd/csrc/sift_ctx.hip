@@ -176,6 +176,10 @@ struct sift_amd_ctx {
     bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
     bool use_cells = true;          // SIFT_AMD_CELLS=0: the extrema scan visits every sample
     std::vector<GraphEntry*> graphs;
+    // keys launched eagerly once: a graph is built when a key comes back, so callers that pass a
+    // new buffer every time do not pay a capture per call
+    struct SeenKey { const float* d_images; int n; int what; };
+    std::vector<SeenKey> seen_once;
     GraphEntry* capturing = nullptr;
     hipStream_t capture_stream = nullptr;
 
@@ -623,7 +627,8 @@ static int run_sequence(sift_amd_ctx* c, const float* d_images, int n, hipStream
 
 // The launch sequence of a batch is ~70 short dependent launches; replaying it as a hipGraph
 // removes the host launch cost between them.  Graphs are cached per (input pointer, batch size,
-// timer mask); anything that cannot be captured falls back to plain launches.
+// timer mask) from the second use of a key on; anything that cannot be captured falls back to
+// plain launches.
 static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, int what)
 {
     // event timers cannot be read back from captured event nodes: timed runs launch eagerly
@@ -632,6 +637,13 @@ static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_
     for (auto* e : c->graphs)
         if (e->d_images == d_images && e->n == n && e->prof_mask == c->prof_mask && e->what == what) { g = e; break; }
     if (!g) {
+        bool seen = false;
+        for (auto& k : c->seen_once) seen = seen || (k.d_images == d_images && k.n == n && k.what == what);
+        if (!seen) {
+            if (c->seen_once.size() >= 16) c->seen_once.erase(c->seen_once.begin());
+            c->seen_once.push_back({d_images, n, what});
+            return run_sequence(c, d_images, n, st, what);
+        }
         if (c->graphs.size() >= 8) {   // drop the oldest entry
             auto* old = c->graphs.front();
             c->graphs.erase(c->graphs.begin());
