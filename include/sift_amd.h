@@ -278,6 +278,22 @@ int sift_amd_match_f32(int device, const float* desc1, int n1, const float* desc
  * device; outputs need room for the keypoint count of img_a (cap entries given). */
 int sift_amd_match_images(sift_amd_ctx* ctx, int img_a, int img_b, float thresh, int flag, int* iA,
                           int* iB, float* dA, float* dB, unsigned char* pass, int cap);
+/* No counterpart in the reference.  sift_amd_match_u8 for callers that cannot allocate: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The call
+ * allocates nothing (no hipMalloc/hipFree, no host allocation): descriptors (n x dim bytes,
+ * row-major) and the five result arrays (n1 entries each, meaning as in sift_amd_match_u8) are
+ * device memory owned by the caller, and the kernels' scratch (packed rows, norms, partial
+ * minima) is a fixed 5.3 MB array inside the library's code object, one copy per GPU.
+ * Limits: n1, n2 <= 8192, dim <= 256, n2 >= 2; anything larger is refused with an error.
+ * Runs on the calling thread's current device; work is queued on `stream` (hipStream_t as
+ * void*, NULL = the null stream) and the results are valid once the stream has caught up.
+ * Returns 0 when queued, a negative value on error.  Every call on one GPU uses that GPU's one
+ * scratch array: calls that overlap on a GPU (different streams without ordering) race; calls
+ * on one stream are ordered.  The first call on a device looks up the array's device address
+ * (hipGetSymbolAddress); make that call outside a graph capture. */
+int sift_amd_match_u8_noalloc(const unsigned char* d_desc1, int n1, const unsigned char* d_desc2,
+                              int n2, int dim, float thresh, int flag, int* d_iA, int* d_iB,
+                              float* d_dA, float* d_dB, unsigned char* d_pass, void* stream);
 /* Frees the context that the reference-named entry points keep per host thread. */
 void sift_amd_release_thread_cache(void);
 

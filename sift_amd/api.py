@@ -86,6 +86,8 @@ def lib():
     L.sift_amd_match_u8.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out
     L.sift_amd_match_f32.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out
     L.sift_amd_match_images.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_int] + match_out + [C.c_int]
+    L.sift_amd_match_u8_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int,
+                                            vp, vp, vp, vp, vp, vp]
     L.sift_amd_release_thread_cache.restype = None
     _lib = L
     return L

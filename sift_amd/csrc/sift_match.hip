@@ -294,6 +294,49 @@ void launch_i8(hipStream_t st, dim3 grid, const signed char* Q, const int* nq, c
     hipLaunchKernelGGL(k_match_i8<KS>, grid, dim3(256), 0, st, Q, nq, T, nt, n2, n2pad, part, nchunk);
 }
 
+// Sizes of the integer path's scratch: packed int8 rows and squared norms of both sets, and the
+// partial minima of every (query, block column).
+struct U8Plan {
+    int dpad, n1pad, n2pad, nchunk;
+    size_t q8_bytes, t8_bytes, nq_bytes, nt_bytes, part_bytes;
+};
+
+U8Plan plan_u8(int n1, int n2, int dim)
+{
+    U8Plan pl;
+    pl.dpad = pad_to(dim, 32); pl.n1pad = pad_to(n1, 32); pl.n2pad = pad_to(n2, 32);
+    pl.nchunk = chunks_for(pl.n1pad / 32, pl.n2pad / 32);
+    pl.q8_bytes = (size_t)pl.n1pad * pl.dpad; pl.t8_bytes = (size_t)pl.n2pad * pl.dpad;
+    pl.nq_bytes = pl.n1pad * sizeof(int); pl.nt_bytes = pl.n2pad * sizeof(int);
+    pl.part_bytes = (size_t)pl.n1pad * pl.nchunk * 2 * sizeof(u64);
+    return pl;
+}
+
+// Queues the whole integer path on `st`: pack both sets, distances + partial minima, final merge.
+// Every byte of the scratch regions that a kernel reads is written earlier in this sequence
+// (padding rows and columns included), so the regions need no clearing between calls.
+void run_u8(hipStream_t st, const U8Plan& pl, const unsigned char* d1, long long stride1, int n1,
+            const unsigned char* d2, long long stride2, int n2, int dim, float thresh, int flag,
+            signed char* q8, int* nq, signed char* t8, int* nt, u64* part,
+            int* o_ia, int* o_ib, float* o_da, float* o_db, unsigned char* o_pass)
+{
+    hipLaunchKernelGGL(k_match_pack_u8, dim3(pl.n1pad), dim3(64), 0, st, d1, stride1, n1, dim, pl.dpad, q8, nq);
+    hipLaunchKernelGGL(k_match_pack_u8, dim3(pl.n2pad), dim3(64), 0, st, d2, stride2, n2, dim, pl.dpad, t8, nt);
+    const dim3 grid(pl.n1pad / 32, pl.nchunk);
+#define SA_MATCH_CASE(K) \
+    case K: launch_i8<K>(st, grid, q8, nq, t8, nt, n2, pl.n2pad, part, pl.nchunk); break;
+    switch (pl.dpad / 32) {
+        SA_MATCH_CASE(1) SA_MATCH_CASE(2) SA_MATCH_CASE(3) SA_MATCH_CASE(4)
+        SA_MATCH_CASE(5) SA_MATCH_CASE(6) SA_MATCH_CASE(7) SA_MATCH_CASE(8)
+    }
+#undef SA_MATCH_CASE
+    MatchSrc src;
+    memset(&src, 0, sizeof(src));
+    src.Q8 = q8; src.nq = nq; src.T8 = t8; src.nt = nt; src.dpad = pl.dpad;
+    hipLaunchKernelGGL(k_match_final, dim3((n1 + 255) / 256), dim3(256), 0, st, part, pl.nchunk, n1, src, thresh,
+                       flag, o_ia, o_ib, o_da, o_db, o_pass);
+}
+
 // d1/d2: device rows.  is_u8: bytes with row strides in bytes, else floats with strides in floats.
 int match_device(hipStream_t st, bool is_u8, const void* d1, long long stride1, int n1, const void* d2, long long stride2,
                  int n2, int dim, float thresh, int flag, int* iA, int* iB, float* dA, float* dB, unsigned char* pass)
@@ -305,44 +348,29 @@ int match_device(hipStream_t st, bool is_u8, const void* d1, long long stride1, 
     if (o_ia.alloc(n1 * sizeof(int)) || o_ib.alloc(n1 * sizeof(int)) || o_da.alloc(n1 * sizeof(float)) ||
         o_db.alloc(n1 * sizeof(float)) || o_pass.alloc(n1))
         return -1;
-    MatchSrc src;
-    memset(&src, 0, sizeof(src));
-    int nchunk;
     if (is_u8) {
-        const int dpad = pad_to(dim, 32), n1pad = pad_to(n1, 32), n2pad = pad_to(n2, 32);
-        if (q8.alloc((size_t)n1pad * dpad) || t8.alloc((size_t)n2pad * dpad) || nq.alloc(n1pad * sizeof(int)) ||
-            nt.alloc(n2pad * sizeof(int)))
+        const U8Plan pl = plan_u8(n1, n2, dim);
+        if (q8.alloc(pl.q8_bytes) || t8.alloc(pl.t8_bytes) || nq.alloc(pl.nq_bytes) || nt.alloc(pl.nt_bytes) ||
+            part.alloc(pl.part_bytes))
             return -1;
-        hipLaunchKernelGGL(k_match_pack_u8, dim3(n1pad), dim3(64), 0, st, (const unsigned char*)d1, stride1, n1, dim, dpad,
-                           q8.as<signed char>(), nq.as<int>());
-        hipLaunchKernelGGL(k_match_pack_u8, dim3(n2pad), dim3(64), 0, st, (const unsigned char*)d2, stride2, n2, dim, dpad,
-                           t8.as<signed char>(), nt.as<int>());
-        nchunk = chunks_for(n1pad / 32, n2pad / 32);
-        if (part.alloc((size_t)n1pad * nchunk * 2 * sizeof(u64))) return -1;
-        const dim3 grid(n1pad / 32, nchunk);
-#define SA_MATCH_CASE(K)                                                                                       \
-    case K: launch_i8<K>(st, grid, q8.as<signed char>(), nq.as<int>(), t8.as<signed char>(), nt.as<int>(), n2, \
-                         n2pad, part.as<u64>(), nchunk); break;
-        switch (dpad / 32) {
-            SA_MATCH_CASE(1) SA_MATCH_CASE(2) SA_MATCH_CASE(3) SA_MATCH_CASE(4)
-            SA_MATCH_CASE(5) SA_MATCH_CASE(6) SA_MATCH_CASE(7) SA_MATCH_CASE(8)
-        }
-#undef SA_MATCH_CASE
-        src.Q8 = q8.as<signed char>(); src.nq = nq.as<int>(); src.T8 = t8.as<signed char>(); src.nt = nt.as<int>();
-        src.dpad = dpad;
+        run_u8(st, pl, (const unsigned char*)d1, stride1, n1, (const unsigned char*)d2, stride2, n2, dim, thresh, flag,
+               q8.as<signed char>(), nq.as<int>(), t8.as<signed char>(), nt.as<int>(), part.as<u64>(),
+               o_ia.as<int>(), o_ib.as<int>(), o_da.as<float>(), o_db.as<float>(), o_pass.as<unsigned char>());
     } else {
+        MatchSrc src;
+        memset(&src, 0, sizeof(src));
         const int n2pad = pad_to(n2, 64);
         if (tt.alloc((size_t)n2pad * dim * sizeof(float))) return -1;
         hipLaunchKernelGGL(k_match_transpose_f32, dim3((n2pad + 255) / 256, dim), dim3(256), 0, st, (const float*)d2,
                            stride2, n2, dim, n2pad, tt.as<float>());
-        nchunk = chunks_for(n1, n2pad / 64);
+        const int nchunk = chunks_for(n1, n2pad / 64);
         if (part.alloc((size_t)n1 * nchunk * 2 * sizeof(u64))) return -1;
         hipLaunchKernelGGL(k_match_f32, dim3(n1, nchunk), dim3(256), 0, st, (const float*)d1, stride1, tt.as<float>(), n2,
                            n2pad, dim, part.as<u64>(), nchunk);
         src.Qf = (const float*)d1; src.q_stride = stride1; src.TT = tt.as<float>(); src.n2pad = n2pad; src.dim = dim;
+        hipLaunchKernelGGL(k_match_final, dim3((n1 + 255) / 256), dim3(256), 0, st, part.as<u64>(), nchunk, n1, src, thresh,
+                           flag, o_ia.as<int>(), o_ib.as<int>(), o_da.as<float>(), o_db.as<float>(), o_pass.as<unsigned char>());
     }
-    hipLaunchKernelGGL(k_match_final, dim3((n1 + 255) / 256), dim3(256), 0, st, part.as<u64>(), nchunk, n1, src, thresh,
-                       flag, o_ia.as<int>(), o_ib.as<int>(), o_da.as<float>(), o_db.as<float>(), o_pass.as<unsigned char>());
     HIP_TRY(hipGetLastError());
     std::vector<unsigned char> hp(n1);
     HIP_TRY(hipMemcpyAsync(iA, o_ia.p, n1 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -399,6 +427,63 @@ extern "C" int sift_amd_match_images(sift_amd_ctx* c, int img_a, int img_b, floa
         return match_device(st, true, (const char*)std_a + 16, sizeof(SaStd), na, (const char*)std_b + 16, sizeof(SaStd),
                             nb, nd, thresh, flag, iA, iB, dA, dB, pass);
     return match_device(st, false, fa, SA_MAX_DESCR, na, fb, SA_MAX_DESCR, nb, nd, thresh, flag, iA, iB, dA, dB, pass);
+}
+
+// ---- allocation-free variant ---------------------------------------------------------------
+// sift_amd_match_u8 for callers that cannot allocate (code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): descriptors and results stay in device memory that the
+// caller owns, and the scratch of the integer path lives in one fixed array of the code object
+// instead of hipMalloc'd buffers.  Each GPU holds its own copy of that array until the process
+// ends; its device address is looked up once per device.
+#define SA_NA_MAX_N 8192      // descriptors per set
+#define SA_NA_MAX_DIM 256     // descriptor length
+namespace {
+constexpr size_t na_align(size_t b) { return (b + 255) & ~(size_t)255; }
+constexpr size_t NA_ROWS_BYTES = na_align((size_t)SA_NA_MAX_N * SA_NA_MAX_DIM);          // int8 rows of one set
+constexpr size_t NA_NORM_BYTES = na_align((size_t)SA_NA_MAX_N * sizeof(int));
+// n1pad * nchunk <= 32 * (2048 + n1pad / 32 - 1) < 65536 + n1pad entries of two keys
+constexpr size_t NA_PART_BYTES = na_align((size_t)(65536 + SA_NA_MAX_N) * 2 * sizeof(u64));
+constexpr size_t NA_OFF_Q8 = 0, NA_OFF_T8 = NA_OFF_Q8 + NA_ROWS_BYTES, NA_OFF_NQ = NA_OFF_T8 + NA_ROWS_BYTES,
+                 NA_OFF_NT = NA_OFF_NQ + NA_NORM_BYTES, NA_OFF_PART = NA_OFF_NT + NA_NORM_BYTES,
+                 NA_TOTAL = NA_OFF_PART + NA_PART_BYTES;                                 // 5.3 MB
+constexpr int NA_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[NA_TOTAL];
+// device address of `scratch` on each GPU (the array's name is only a host-side handle)
+static unsigned char* g_na_ptr[NA_MAX_DEVICES];
+
+extern "C" int sift_amd_match_u8_noalloc(const unsigned char* d_desc1, int n1, const unsigned char* d_desc2, int n2,
+                                         int dim, float thresh, int flag, int* d_iA, int* d_iB, float* d_dA,
+                                         float* d_dB, unsigned char* d_pass, void* stream)
+{
+    if (n1 < 0 || n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
+    if (dim < 1 || dim > SA_NA_MAX_DIM) { sa_set_error("descriptor length %d outside 1..%d", dim, SA_NA_MAX_DIM); return -1; }
+    if (n1 > SA_NA_MAX_N || n2 > SA_NA_MAX_N) {
+        sa_set_error("allocation-free matching takes at most %d descriptors per set (got %d and %d)", SA_NA_MAX_N, n1, n2);
+        return -1;
+    }
+    if (n1 == 0) return 0;
+    const U8Plan pl = plan_u8(n1, n2, dim);
+    if (pl.q8_bytes > NA_ROWS_BYTES || pl.t8_bytes > NA_ROWS_BYTES || pl.nq_bytes > NA_NORM_BYTES ||
+        pl.nt_bytes > NA_NORM_BYTES || pl.part_bytes > NA_PART_BYTES) {
+        sa_set_error("allocation-free matching: %d x %d descriptors of length %d exceed the fixed scratch", n1, n2, dim);
+        return -1;
+    }
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NA_MAX_DEVICES) { sa_set_error("device index %d outside 0..%d", dev, NA_MAX_DEVICES - 1); return -1; }
+    unsigned char* base = __atomic_load_n(&g_na_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!base) {
+        HIP_TRY(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(scratch)));
+        if (!base) { sa_set_error("hipGetSymbolAddress returned no address for the scratch array"); return -1; }
+        __atomic_store_n(&g_na_ptr[dev], base, __ATOMIC_RELEASE);
+    }
+    run_u8((hipStream_t)stream, pl, d_desc1, dim, n1, d_desc2, dim, n2, dim, thresh, flag,
+           (signed char*)(base + NA_OFF_Q8), (int*)(base + NA_OFF_NQ), (signed char*)(base + NA_OFF_T8),
+           (int*)(base + NA_OFF_NT), (u64*)(base + NA_OFF_PART), d_iA, d_iB, d_dA, d_dB, d_pass);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // ---- reference-named entry points (lib_matching.h) -----------------------------------------
