@@ -20,6 +20,7 @@
 #ifndef SIFT_AMD_H
 #define SIFT_AMD_H
 
+#include <stddef.h>
 #include <stdio.h>
 
 #ifdef __cplusplus
@@ -158,7 +159,13 @@ void save_pairs_extra(const char* name, const struct sift_keypoints* k1,
 /* ===================================================================== Part 2 == */
 /* No counterpart in the reference: batched, context-based interface.  Functions return 0
  * on success and a negative value on failure; sift_amd_last_error() describes the failure
- * of the calling thread's last call. */
+ * of the calling thread's last call.
+ * Devices and streams: every entry point runs on the context's device and leaves the calling
+ * thread's current HIP device as it found it.  A `stream` argument must belong to the context's
+ * device.  The runs of one context share its pool, so they execute one after the other: a run
+ * queued on another stream than the previous run first waits for the previous run.  When a
+ * list of a run overflows its capacity, every call that reads that run's results returns -2
+ * until the next run. */
 
 typedef struct sift_amd_ctx sift_amd_ctx;
 
@@ -241,6 +248,11 @@ int sift_amd_fetch_keypoints(sift_amd_ctx* ctx, int img, struct sift_keypoint_st
  * (caller frees with free()); counts[i] receives the per-image counts. */
 int sift_amd_gather_keypoints(sift_amd_ctx* ctx, struct sift_keypoint_std** out, int* counts);
 
+/* Same into a caller-owned buffer of max_records records (pinned host memory makes the copy
+ * asynchronous-capable and fastest); nothing is allocated.  Returns the number of records. */
+int sift_amd_gather_keypoints_into(sift_amd_ctx* ctx, struct sift_keypoint_std* out, int max_records,
+                                   int* counts);
+
 /* Stage-level access for parity tooling.  stage_sizes[0..5] are the sizes of the lists
  * A..F of lib_sift_anatomy.c:843-848, extrema_per_octave the discrete-extrema counts.
  * Without SIFT_AMD_KEEP_ALL_EXTREMA the scan skips regions in which no sample passes the
@@ -297,11 +309,24 @@ int sift_amd_match_u8_noalloc(const unsigned char* d_desc1, int n1, const unsign
 /* Frees the context that the reference-named entry points keep per host thread. */
 void sift_amd_release_thread_cache(void);
 
+/* Measurement aid: the rate (read + written bytes per second, in GB/s) that a plain copy kernel
+ * reaches on `device` between two freshly allocated buffers of `bytes` bytes, averaged over
+ * `reps` launches.  A practical ceiling to put beside the nominal HBM peak. */
+int sift_amd_copy_ceiling(int device, size_t bytes, int reps, double* gb_per_s);
+/* Likewise for arithmetic: the rate, in 1e9 lane-operations per second, at which `device`
+ * executes float32 multiplies and adds that are not fused (each rounded on its own, as the
+ * blur of lib_discrete.c:286-291 prescribes), from registers, with nothing else in the way. */
+int sift_amd_valu_ceiling(int device, int reps, double* lane_gops);
+
 /* Event timers: enable for a mask of (1 << SIFT_AMD_K_*) classes; read accumulates since the
  * last reset.  ms = summed kernel durations, launches = number of launches timed. */
 int sift_amd_profile_enable(sift_amd_ctx* ctx, unsigned mask);
 int sift_amd_profile_read(sift_amd_ctx* ctx, int kernel_class, int octave /* -1 = all */,
                           double* ms, long long* launches, int reset);
+/* The blur launches (classes SIFT_AMD_K_BLUR_FUSED / SIFT_AMD_K_OVERSAMPLE) one by one: the launch
+ * that writes image `scale` of the Gaussian stack of `octave` (scale 0 = the seed launch). */
+int sift_amd_profile_read_blur(sift_amd_ctx* ctx, int octave, int scale, double* ms, long long* launches,
+                               int reset);
 
 #ifdef __cplusplus
 }

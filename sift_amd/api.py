@@ -72,6 +72,10 @@ def lib():
     L.sift_amd_keypoint_counts.argtypes = [vp, abi.c_int_p]
     L.sift_amd_fetch_keypoints.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.sift_amd_gather_keypoints.argtypes = [vp, P(vp), abi.c_int_p]
+    L.sift_amd_gather_keypoints_into.argtypes = [vp, vp, C.c_int, abi.c_int_p]
+    L.sift_amd_copy_ceiling.argtypes = [C.c_int, C.c_size_t, C.c_int, P(C.c_double)]
+    L.sift_amd_valu_ceiling.argtypes = [C.c_int, C.c_int, P(C.c_double)]
+    L.sift_amd_profile_read_blur.argtypes = [vp, C.c_int, C.c_int, P(C.c_double), P(C.c_longlong), C.c_int]
     L.sift_amd_stage_counts.argtypes = [vp, C.c_int, abi.c_int_p, abi.c_int_p]
     L.sift_amd_fetch_candidates.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
     L.sift_amd_copy_scalespace.argtypes = [vp, C.c_int, C.c_int, C.c_int, abi.c_float_p]
@@ -99,6 +103,22 @@ def _err(what):
 
 def device_count():
     return lib().sift_amd_device_count()
+
+
+def valu_ceiling(device=0, reps=3):
+    """1e9 lane-operations/s of non-fused float32 multiplies and adds on `device`."""
+    out = C.c_double()
+    if lib().sift_amd_valu_ceiling(device, reps, C.byref(out)):
+        raise _err("sift_amd_valu_ceiling")
+    return out.value
+
+
+def copy_ceiling(device=0, nbytes=2 << 30, reps=5):
+    """GB/s (read + written) of a plain copy kernel on `device`: a practical HBM ceiling."""
+    out = C.c_double()
+    if lib().sift_amd_copy_ceiling(device, nbytes, reps, C.byref(out)):
+        raise _err("sift_amd_copy_ceiling")
+    return out.value
 
 
 class Context:
@@ -223,6 +243,15 @@ class Context:
         C.CDLL(None).free(out)
         return arr, counts
 
+    def gather_into(self, buf):
+        """Host gather into a caller-owned array of 144-byte records (e.g. pinned memory).
+        Returns (view of the filled part, per-image counts)."""
+        cnt = (C.c_int * max(self.last_n, 1))()
+        total = self.L.sift_amd_gather_keypoints_into(self.ptr, buf.ctypes.data, len(buf), cnt)
+        if total < 0:
+            raise _err("sift_amd_gather_keypoints_into")
+        return buf[:total], np.array(cnt[:self.last_n], np.int64)
+
     def extras(self, img=0):
         n = int(self.counts()[img])
         nb = self.params.n_bins
@@ -280,6 +309,13 @@ class Context:
         n = C.c_longlong()
         if self.L.sift_amd_profile_read(self.ptr, cls, octave, C.byref(ms), C.byref(n), int(reset)):
             raise _err("sift_amd_profile_read")
+        return ms.value, n.value
+
+    def profile_read_blur(self, octave, scale, reset=False):
+        ms = C.c_double()
+        n = C.c_longlong()
+        if self.L.sift_amd_profile_read_blur(self.ptr, octave, scale, C.byref(ms), C.byref(n), int(reset)):
+            raise _err("sift_amd_profile_read_blur")
         return ms.value, n.value
 
     # ---- sizes of the work (for roofline accounting)

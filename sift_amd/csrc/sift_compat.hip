@@ -29,35 +29,118 @@ static int env_device()
 
 // ------------------------------------------------------ per-thread context --
 // The reference API is stateless; allocating the HBM pool on every call would dominate
-// small calls, so each host thread keeps the context of its last (size, parameters, mode).
+// small calls, so each host thread keeps the contexts of its last few (size, parameters,
+// mode) combinations: a host that alternates sift_anatomy() with the flat API, or
+// scalespace_compute() with anything, does not rebuild a pool per call.
 struct CachedCtx {
     sift_amd_ctx* ctx = nullptr;
     int w = 0, h = 0, flags = 0, device = -1;
     sift_parameters p;
-    bool lowe = true;
+    bool lowe = true;          // geometry from the parameters (else: the caller's scale-space)
     SaLayout L;
     float sigma_in = 0;
-    ~CachedCtx() { if (ctx) sift_amd_destroy(ctx); }
+    int cap = 0, fcap = 0;     // list capacities the context was created with (0 = defaults)
+    unsigned long used = 0;
 };
-static thread_local CachedCtx g_cache;
+struct ThreadCache {
+    static constexpr int N = 4;
+    CachedCtx e[N];
+    unsigned long tick = 0;
+    // device scratch of scalespace_compute_gradient: one stack in, two out
+    float* d_grad = nullptr;
+    size_t grad_floats = 0;
+    int grad_device = -1;
+    void release()
+    {
+        for (auto& c : e)
+            if (c.ctx) { sift_amd_destroy(c.ctx); c.ctx = nullptr; }
+        if (d_grad) {
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            (void)hipSetDevice(grad_device);
+            (void)hipFree(d_grad);
+            if (prev >= 0) (void)hipSetDevice(prev);
+            d_grad = nullptr; grad_floats = 0;
+        }
+    }
+    ~ThreadCache() { release(); }
+};
+static thread_local ThreadCache g_cache;
 
-static sift_amd_ctx* get_ctx(int w, int h, const sift_parameters* p, int flags)
+static CachedCtx* cache_slot()       // an empty slot, else the least recently used one (emptied)
 {
-    CachedCtx& cc = g_cache;
+    CachedCtx* pick = &g_cache.e[0];
+    for (auto& c : g_cache.e) {
+        if (!c.ctx) { pick = &c; break; }
+        if (c.used < pick->used) pick = &c;
+    }
+    if (pick->ctx) { sift_amd_destroy(pick->ctx); pick->ctx = nullptr; }
+    return pick;
+}
+
+// cap/fcap: list capacities (0 = defaults); a cached context with at least these is reused
+static sift_amd_ctx* get_ctx(int w, int h, const sift_parameters* p, int flags, int cap = 0, int fcap = 0)
+{
     const int dev = env_device();
-    if (cc.ctx && cc.lowe && cc.w == w && cc.h == h && cc.flags == flags && cc.device == dev &&
-        memcmp(&cc.p, p, sizeof *p) == 0)
-        return cc.ctx;
-    if (cc.ctx) { sift_amd_destroy(cc.ctx); cc.ctx = nullptr; }
-    sift_amd_ctx* c = sift_amd_create(dev, w, h, 1, p, flags);
+    for (auto& c : g_cache.e)
+        if (c.ctx && c.lowe && c.w == w && c.h == h && c.flags == flags && c.device == dev &&
+            memcmp(&c.p, p, sizeof *p) == 0 && c.cap >= cap && c.fcap >= fcap) {
+            c.used = ++g_cache.tick;
+            return c.ctx;
+        }
+    // a context of the same key with smaller lists is replaced, not kept beside the new one
+    for (auto& c : g_cache.e)
+        if (c.ctx && c.lowe && c.w == w && c.h == h && c.flags == flags && c.device == dev &&
+            memcmp(&c.p, p, sizeof *p) == 0) { sift_amd_destroy(c.ctx); c.ctx = nullptr; }
+    CachedCtx* cc = cache_slot();
+    SaLayout L;
+    memset(&L, 0, sizeof L);
+    const int n_oct = sa_number_of_octaves(w, h, p);
+    if (p->n_spo < 1 || p->n_spo + 3 > SA_MAX_SCA || n_oct < 1 || n_oct > SA_MAX_OCT) {
+        sa_set_error("image %dx%d with n_spo %d gives %d octaves (supported: 1..%d octaves, n_spo 1..%d)",
+                     w, h, p->n_spo, n_oct, SA_MAX_OCT, SA_MAX_SCA - 3);
+        die("cannot create context");
+    }
+    sa_layout_lowe(&L, n_oct, p->n_spo, w, h, p->delta_min, p->sigma_min);
+    sift_amd_ctx* c = sa_create_from_layout(dev, w, h, 1, p, &L, p->sigma_in, flags, cap, fcap);
     if (!c) die("cannot create context");
-    cc.ctx = c; cc.w = w; cc.h = h; cc.flags = flags; cc.device = dev; cc.p = *p; cc.lowe = true;
+    cc->ctx = c; cc->w = w; cc->h = h; cc->flags = flags; cc->device = dev; cc->p = *p; cc->lowe = true;
+    int kcap;
+    sa_ctx_limits(c, &cc->cap, &cc->fcap, &kcap);
+    cc->used = ++g_cache.tick;
     return c;
 }
 
-extern "C" void sift_amd_release_thread_cache(void)
+// Context for a caller-supplied scale-space geometry (scalespace_compute).
+static sift_amd_ctx* get_ctx_layout(int w, int h, const sift_parameters* p, const SaLayout* L, float sigma_in)
 {
-    if (g_cache.ctx) { sift_amd_destroy(g_cache.ctx); g_cache.ctx = nullptr; }
+    const int dev = env_device();
+    for (auto& c : g_cache.e)
+        if (c.ctx && !c.lowe && c.w == w && c.h == h && c.device == dev && c.sigma_in == sigma_in &&
+            memcmp(&c.L, L, sizeof *L) == 0) {
+            c.used = ++g_cache.tick;
+            return c.ctx;
+        }
+    CachedCtx* cc = cache_slot();
+    sift_amd_ctx* c = sa_create_from_layout(dev, w, h, 1, p, L, sigma_in, 0, 0, 0);
+    if (!c) die("scalespace_compute");
+    cc->ctx = c; cc->w = w; cc->h = h; cc->flags = 0; cc->device = dev; cc->p = *p; cc->lowe = false;
+    cc->L = *L; cc->sigma_in = sigma_in; cc->cap = cc->fcap = 0; cc->used = ++g_cache.tick;
+    return c;
+}
+
+extern "C" void sift_amd_release_thread_cache(void) { g_cache.release(); }
+
+// A list of the last run overflowed: the capacities that certainly hold it.  The scan counts
+// every candidate it meets, also those beyond the list's end, so `cap` is exact; how many
+// survive is only known for the stored ones, so the survivor lists get room for all of them.
+static void grown_caps(sift_amd_ctx* c, int* cap, int* fcap)
+{
+    int cur_cap, cur_fcap, cur_kcap;
+    sa_ctx_limits(c, &cur_cap, &cur_fcap, &cur_kcap);
+    const int n_cand = sa_ctx_candidates_seen(c);
+    *cap = n_cand > cur_cap ? n_cand : cur_cap;
+    *fcap = *cap;
 }
 
 // -------------------------------------------------------------- containers --
@@ -217,18 +300,27 @@ static void download_stack(sift_amd_ctx* c, int which, struct sift_scalespace* s
         if (sift_amd_copy_scalespace(c, 0, which, o, ss->octaves[o]->imStack)) die("copy scale-space");
 }
 
-// d/di and d/dj of every image of a host scale-space (lib_sift_anatomy.c:202-218).
+// d/di and d/dj of every image of a host scale-space (lib_sift_anatomy.c:202-218).  The device
+// scratch (one stack in, two out, sized for the largest octave) is kept per host thread.
 static void gradient_stacks(const struct sift_scalespace* s, struct sift_scalespace* sx, struct sift_scalespace* sy)
 {
-    if (hipSetDevice(env_device()) != hipSuccess) { sa_set_error("hipSetDevice failed"); die("gradient"); }
+    const int dev = env_device();
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(dev) != hipSuccess) { sa_set_error("hipSetDevice failed"); die("gradient"); }
     size_t biggest = 0;
     for (int o = 0; o < s->nOct; o++) {
         const struct octa* oc = s->octaves[o];
         biggest = std::max(biggest, (size_t)oc->nSca * oc->w * oc->h);
     }
-    float *d_im = nullptr, *d_gi = nullptr, *d_gj = nullptr;
-    if (hipMalloc((void**)&d_im, biggest * 4) != hipSuccess || hipMalloc((void**)&d_gi, biggest * 4) != hipSuccess ||
-        hipMalloc((void**)&d_gj, biggest * 4) != hipSuccess) { sa_set_error("hipMalloc failed"); die("gradient"); }
+    ThreadCache& tc = g_cache;
+    if (tc.grad_floats < biggest || tc.grad_device != dev) {
+        if (tc.d_grad) { (void)hipSetDevice(tc.grad_device); (void)hipFree(tc.d_grad); (void)hipSetDevice(dev); }
+        tc.d_grad = nullptr; tc.grad_floats = 0;
+        if (hipMalloc((void**)&tc.d_grad, 3 * biggest * sizeof(float)) != hipSuccess) { sa_set_error("hipMalloc failed"); die("gradient"); }
+        tc.grad_floats = biggest; tc.grad_device = dev;
+    }
+    float *d_im = tc.d_grad, *d_gi = tc.d_grad + tc.grad_floats, *d_gj = tc.d_grad + 2 * tc.grad_floats;
     for (int o = 0; o < s->nOct; o++) {
         const struct octa* oc = s->octaves[o];
         const size_t bytes = (size_t)oc->nSca * oc->w * oc->h * 4;
@@ -238,7 +330,7 @@ static void gradient_stacks(const struct sift_scalespace* s, struct sift_scalesp
         ok = ok && hipMemcpy(sy->octaves[o]->imStack, d_gj, bytes, hipMemcpyDeviceToHost) == hipSuccess;
         if (!ok) { sa_set_error("gradient transfer failed: %s", hipGetErrorString(hipGetLastError())); die("gradient"); }
     }
-    (void)hipFree(d_im); (void)hipFree(d_gi); (void)hipFree(d_gj);
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
 }
 
 // ---------------------------------------------------------- reference API --
@@ -256,21 +348,30 @@ static struct sift_keypoints* run_full(const float* x, int w, int h, const sift_
                                        struct sift_scalespace** ss, int n_ss, struct sift_keypoints** kk,
                                        int n_lists, bool describe)
 {
-    sift_amd_ctx* c = get_ctx(w, h, p, SIFT_AMD_KEEP_ALL_EXTREMA | SIFT_AMD_KEEP_SCALESPACE);
-    hipStream_t st = sa_ctx_stream(c);
-    if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
-        sa_set_error("input upload failed");
-        die("sift_anatomy");
+    // The reference's lists grow as needed; here a run whose lists overflow is repeated once in
+    // a context whose lists hold what the first run counted.
+    sift_amd_ctx* c = nullptr;
+    int cap = 0, fcap = 0;
+    for (int attempt = 0;; attempt++) {
+        c = get_ctx(w, h, p, SIFT_AMD_KEEP_ALL_EXTREMA | SIFT_AMD_KEEP_SCALESPACE, cap, fcap);
+        hipStream_t st = sa_ctx_stream(c);
+        if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+            sa_set_error("input upload failed");
+            die("sift_anatomy");
+        }
+        int rc;
+        if (describe) {
+            rc = sift_amd_detect_device(c, sa_ctx_input_buffer(c), 1, nullptr);
+        } else {
+            rc = sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr);
+            if (!rc) rc = sa_run_detect(c, 1, st);
+        }
+        if (rc) die("pipeline");
+        rc = sa_sync_counters(c);
+        if (rc == -2 && attempt == 0) { grown_caps(c, &cap, &fcap); continue; }
+        if (rc) die("pipeline");
+        break;
     }
-    int rc;
-    if (describe) {
-        rc = sift_amd_detect_device(c, sa_ctx_input_buffer(c), 1, nullptr);
-    } else {
-        rc = sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr);
-        if (!rc) rc = sa_run_detect(c, 1, st);
-    }
-    if (rc) die("pipeline");
-    if (sa_sync_counters(c)) die("pipeline");
 
     const SaLayout* L = sa_ctx_layout(c);
     // scale-spaces
@@ -361,7 +462,7 @@ extern "C" struct sift_keypoints* sift_anatomy_without_description(const float* 
 static void describe_list(const float* x, int w, int h, const sift_parameters* p, struct sift_keypoints* k,
                           bool find_orientation)
 {
-    sift_amd_ctx* c = get_ctx(w, h, p, 0);
+    sift_amd_ctx* c = get_ctx(w, h, p, 0, 0, k->size);      // survivor lists with room for the caller's keypoints
     hipStream_t st = sa_ctx_stream(c);
     if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
         sa_set_error("input upload failed");
@@ -435,15 +536,16 @@ extern "C" void scalespace_compute(struct sift_scalespace* ss, const float* imag
     sift_parameters p;
     sa_default_parameters(&p);
     p.n_spo = L.n_sca - 3; p.delta_min = L.delta[0]; p.sigma_min = L.sigmas[0][0]; p.sigma_in = sigma_in;
-    sift_amd_ctx* c = sa_create_from_layout(env_device(), im_w, im_h, 1, &p, &L, sigma_in, SIFT_AMD_KEEP_SCALESPACE);
-    if (!c) die("scalespace_compute");
-    if (hipMemcpy(sa_ctx_input_buffer(c), image, (size_t)im_w * im_h * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    // only the Gaussian stack is handed back: the context stores no DoG images, and it stays
+    // cached for the next call with this geometry
+    sift_amd_ctx* c = get_ctx_layout(im_w, im_h, &p, &L, sigma_in);
+    if (hipMemcpyAsync(sa_ctx_input_buffer(c), image, (size_t)im_w * im_h * sizeof(float), hipMemcpyHostToDevice,
+                       sa_ctx_stream(c)) != hipSuccess) {
         sa_set_error("input upload failed");
         die("scalespace_compute");
     }
     if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr)) die("scalespace_compute");
     download_stack(c, 0, ss);
-    sift_amd_destroy(c);
 }
 
 extern "C" void scalespace_compute_gradient(const struct sift_scalespace* s, struct sift_scalespace* sx,
@@ -458,10 +560,16 @@ extern "C" struct sift_keypoint_std* sift_compute_features(const float* x, int w
 {
     sift_parameters p;
     sa_default_parameters(&p);
-    sift_amd_ctx* c = get_ctx(w, h, &p, 0);
-    if (sift_amd_detect_host(c, x, 1)) die("sift_compute_features");
-    int cnt = 0;
-    if (sift_amd_keypoint_counts(c, &cnt)) die("sift_compute_features");
+    sift_amd_ctx* c = nullptr;
+    int cnt = 0, cap = 0, fcap = 0;
+    for (int attempt = 0;; attempt++) {
+        c = get_ctx(w, h, &p, 0, cap, fcap);
+        if (sift_amd_detect_host(c, x, 1)) die("sift_compute_features");
+        const int rc = sift_amd_keypoint_counts(c, &cnt);
+        if (rc == -2 && attempt == 0) { grown_caps(c, &cap, &fcap); continue; }
+        if (rc) die("sift_compute_features");
+        break;
+    }
     struct sift_keypoint_std* k = (struct sift_keypoint_std*)must_malloc((size_t)cnt * sizeof *k);
     if (cnt && sift_amd_fetch_keypoints(c, 0, k, nullptr, cnt) != cnt) die("sift_compute_features");
     *n = cnt;
@@ -474,15 +582,21 @@ extern "C" struct sift_keypoint_std* sift_compute_points(const float* x, int w, 
 {
     sift_parameters p;
     sa_default_parameters(&p);
-    sift_amd_ctx* c = get_ctx(w, h, &p, 0);
-    hipStream_t st = sa_ctx_stream(c);
-    if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
-        sa_set_error("input upload failed");
-        die("sift_compute_points");
+    sift_amd_ctx* c = nullptr;
+    int sizes[6], ext[SIFT_AMD_MAX_OCT], cap = 0, fcap = 0;
+    for (int attempt = 0;; attempt++) {
+        c = get_ctx(w, h, &p, 0, cap, fcap);
+        hipStream_t st = sa_ctx_stream(c);
+        if (hipMemcpyAsync(sa_ctx_input_buffer(c), x, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess) {
+            sa_set_error("input upload failed");
+            die("sift_compute_points");
+        }
+        if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr) || sa_run_detect(c, 1, st)) die("sift_compute_points");
+        const int rc = sift_amd_stage_counts(c, 0, sizes, ext);
+        if (rc == -2 && attempt == 0) { grown_caps(c, &cap, &fcap); continue; }
+        if (rc) die("sift_compute_points");
+        break;
     }
-    if (sift_amd_scalespace_device(c, sa_ctx_input_buffer(c), 1, nullptr) || sa_run_detect(c, 1, st)) die("sift_compute_points");
-    int sizes[6], ext[SIFT_AMD_MAX_OCT];
-    if (sift_amd_stage_counts(c, 0, sizes, ext)) die("sift_compute_points");
     const int nc = sift_amd_fetch_candidates(c, 0, nullptr, nullptr, nullptr, 0);   // list B
     if (nc < 0) die("sift_compute_points");
     std::vector<sift_amd_key> ref(nc);

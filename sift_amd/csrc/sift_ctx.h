@@ -1,5 +1,5 @@
 // Internal interface between the pipeline (sift_ctx.hip) and the reference-named C API
-// (sift_compat.cpp).  Not part of the public ABI.
+// (sift_compat.hip).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -20,7 +20,7 @@ float sa_convert_threshold(const sift_parameters* p);
 void sa_layout_lowe(SaLayout* L, int n_oct, int n_spo, int im_w, int im_h, float delta_min, float sigma_min);
 
 sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batch, const sift_parameters* p,
-                                    const SaLayout* L, float sigma_in, int flags);
+                                    const SaLayout* L, float sigma_in, int flags, int cap_req, int fcap_req);
 int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st);
 int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st);
 int sa_run_orient(sift_amd_ctx* c, int n, hipStream_t st, bool given, int mode);
@@ -28,6 +28,7 @@ int sa_run_describe(sift_amd_ctx* c, int n, hipStream_t st);
 int sa_sync_counters(sift_amd_ctx* c);
 int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orientation);
 int sa_ctx_limits(const sift_amd_ctx* c, int* cap, int* fcap, int* kcap);
+int sa_ctx_candidates_seen(const sift_amd_ctx* c);
 const SaLayout* sa_ctx_layout(const sift_amd_ctx* c);
 const sift_parameters* sa_ctx_params(const sift_amd_ctx* c);
 float* sa_ctx_input_buffer(sift_amd_ctx* c);

@@ -39,6 +39,25 @@ extern "C" const char* sift_amd_last_error(void) { return g_err; }
         }                                                                                  \
     } while (0)
 
+// Makes `dev` the calling thread's current HIP device for the guard's lifetime and puts the
+// caller's device back afterwards, so a host thread that drives several GPUs (or shares the
+// thread with another HIP user) does not find its current device changed by a library call.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+        else prev = -1;                      // nothing to restore
+        if (!ok) sa_set_error("hipSetDevice(%d) failed", dev);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define SA_ON_DEVICE(c)                     \
+    DeviceGuard dev_guard_((c)->device);    \
+    if (!dev_guard_.ok) return -1
+
 extern "C" int sift_amd_device_count(void)
 {
     int n = 0;
@@ -122,7 +141,7 @@ struct BlurSpec {
     float* taps_dev;
 };
 
-struct ProfEvent { hipEvent_t a, b; int cls, oct; };
+struct ProfEvent { hipEvent_t a, b; int cls, oct, sca; };
 
 struct sift_amd_ctx {
     int device = 0;
@@ -134,11 +153,12 @@ struct sift_amd_ctx {
     SaScalars sc;
     BlurSpec seed;
     BlurSpec step[SA_MAX_OCT][SA_MAX_SCA];
-    bool fused_blur = true;         // SIFT_AMD_BLUR=split selects the two-kernel form
     hipStream_t own_stream = nullptr;
     hipStream_t last_stream = nullptr;
     int last_n = 0;
 
+    // d_seed (oversampled input) and d_tmp (column-pass image) only exist when some blur radius is
+    // outside the register-window range and takes the any-radius two-launch form
     float *d_in = nullptr, *d_seed = nullptr, *d_tmp = nullptr;
     // marks of the 8-row x 64-column DoG cells that hold a sample passing the first contrast
     // test, per octave [batch][ceil(h/8)][ceil(w/64)], one allocation (d_cells[0] is its start)
@@ -166,6 +186,7 @@ struct sift_amd_ctx {
     float* d_descr = nullptr;
     int* h_counters = nullptr;      // pinned
     bool counters_valid = false;
+    bool overflowed = false;        // a list of the last run ran out of room (sticky until the next run)
     std::vector<void*> allocs;
 
     // cached hipGraphs of the whole launch sequence, keyed by (input pointer, batch, timers)
@@ -188,6 +209,9 @@ struct sift_amd_ctx {
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[SIFT_AMD_K_COUNT][SA_MAX_OCT + 1] = {};
     long long prof_n[SIFT_AMD_K_COUNT][SA_MAX_OCT + 1] = {};
+    // the blur launches once more per (octave, image index of the stack they write)
+    double prof_blur_ms[SA_MAX_OCT][SA_MAX_SCA] = {};
+    long long prof_blur_n[SA_MAX_OCT][SA_MAX_SCA] = {};
 };
 
 template <typename T>
@@ -233,8 +257,10 @@ static long long total_pixels(const SaLayout& L)
     return n;
 }
 
+// cap_req / fcap_req: capacities of the candidate and survivor lists per image (0 = defaults
+// derived from the pyramid size).
 sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batch, const sift_parameters* p,
-                                    const SaLayout* L, float sigma_in, int flags)
+                                    const SaLayout* L, float sigma_in, int flags, int cap_req, int fcap_req)
 {
     if (max_batch < 1 || im_w < 1 || im_h < 1) { sa_set_error("invalid size or batch"); return nullptr; }
     if (L->n_oct < 1 || L->n_oct > SA_MAX_OCT) {
@@ -257,13 +283,13 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
                      im_w, im_h, L->w[0], L->h[0]);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) { sa_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    DeviceGuard dev_guard_(device);
+    if (!dev_guard_.ok) return nullptr;
 
     sift_amd_ctx* c = new sift_amd_ctx();
     c->device = device; c->im_w = im_w; c->im_h = im_h; c->batch = max_batch; c->flags = flags;
     c->p = *p; c->L = *L; c->sigma_in = sigma_in;
     auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
-    if (const char* m = getenv("SIFT_AMD_BLUR")) c->fused_blur = strcmp(m, "split") != 0;
     if (const char* m = getenv("SIFT_AMD_GRAPH")) c->use_graph = atoi(m) != 0;
     if (const char* m = getenv("SIFT_AMD_CELLS")) c->use_cells = atoi(m) != 0;
 
@@ -307,8 +333,16 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     const long long ntot = total_pixels(*L);
     const long long B = max_batch;
     if (dev_alloc(c, &c->d_in, (size_t)(B * im_w * im_h))) return fail();
-    if (dev_alloc(c, &c->d_seed, (size_t)(B * n0))) return fail();
-    if (dev_alloc(c, &c->d_tmp, (size_t)(B * n0))) return fail();
+    {
+        auto slow = [](const BlurSpec& b) { return b.radius < 1 || b.radius > SA_MAX_RADIUS_FAST; };
+        bool any_slow = slow(c->seed);
+        for (int o = 0; o < L->n_oct; o++)
+            for (int s = 1; s < L->n_sca; s++) any_slow = any_slow || slow(c->step[o][s]);
+        if (any_slow) {
+            if (dev_alloc(c, &c->d_seed, (size_t)(B * n0))) return fail();
+            if (dev_alloc(c, &c->d_tmp, (size_t)(B * n0))) return fail();
+        }
+    }
     memset(&c->pyr, 0, sizeof c->pyr);
     c->pyr.n_oct = L->n_oct; c->pyr.n_sca = L->n_sca; c->pyr.im_w = im_w; c->pyr.im_h = im_h;
     for (int o = 0; o < L->n_oct; o++) {
@@ -326,14 +360,17 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     long long cap = (flags & SIFT_AMD_KEEP_ALL_EXTREMA) ? ntot / 8 : ntot / 64;
     cap = std::max<long long>(cap, 16384);
     cap = std::min<long long>(cap, 1 << 24);
+    if (cap_req > 0) cap = std::min<long long>(std::max<long long>(cap, cap_req), 1 << 26);
     c->cap = (int)cap;
     c->fcap = (int)std::max<long long>(4096, cap / 4);
+    if (fcap_req > 0) c->fcap = std::min(std::max(c->fcap, fcap_req), 1 << 26);
     // SIFT_AMD_CAP=<n>: list capacities forced small, to exercise the overflow report
-    if (const char* m = getenv("SIFT_AMD_CAP")) {
+    if (const char* m = (cap_req > 0 || fcap_req > 0) ? nullptr : getenv("SIFT_AMD_CAP")) {
         c->cap = std::max(64, atoi(m));
         c->fcap = std::max(16, c->cap / 4);
     }
-    c->kcap = 2 * c->fcap;
+    // room for two orientations per survivor on average; four when the caller sized the lists
+    c->kcap = (fcap_req > 0 ? 4 : 2) * c->fcap;
     if (dev_alloc(c, &c->d_ckey, (size_t)(B * c->cap))) return fail();
     if (dev_alloc(c, &c->d_cval, (size_t)(B * c->cap))) return fail();
     if (dev_alloc(c, &c->d_ref, (size_t)(B * c->cap))) return fail();
@@ -379,13 +416,13 @@ extern "C" sift_amd_ctx* sift_amd_create(int device, int w, int h, int max_batch
         return nullptr;
     }
     sa_layout_lowe(&L, n_oct, p.n_spo, w, h, p.delta_min, p.sigma_min);
-    return sa_create_from_layout(device, w, h, max_batch, &p, &L, p.sigma_in, flags);
+    return sa_create_from_layout(device, w, h, max_batch, &p, &L, p.sigma_in, flags, 0, 0);
 }
 
 extern "C" void sift_amd_destroy(sift_amd_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceGuard dev_guard_(c->device);
     hipDeviceSynchronize();
     for (auto& e : c->prof_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : c->prof_pool) hipEventDestroy(e);
@@ -421,7 +458,7 @@ extern "C" int sift_amd_get_geometry(const sift_amd_ctx* c, sift_amd_geometry* g
 
 struct ProfScope {
     sift_amd_ctx* c; hipStream_t st; ProfEvent ev; bool on;
-    ProfScope(sift_amd_ctx* c_, hipStream_t st_, int cls, int oct) : c(c_), st(st_), on(false)
+    ProfScope(sift_amd_ctx* c_, hipStream_t st_, int cls, int oct, int sca = -1) : c(c_), st(st_), on(false)
     {
         if (!(c->prof_mask & (1u << cls))) return;
         auto get = [&]() {
@@ -430,7 +467,7 @@ struct ProfScope {
             else hipEventCreate(&e);
             return e;
         };
-        ev.a = get(); ev.b = get(); ev.cls = cls; ev.oct = oct;
+        ev.a = get(); ev.b = get(); ev.cls = cls; ev.oct = oct; ev.sca = sca;
         hipEventRecord(ev.a, st);
         on = true;
     }
@@ -449,6 +486,7 @@ static void prof_collect(sift_amd_ctx* c)
         float ms = 0.f;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             c->prof_ms[e.cls][e.oct] += ms; c->prof_n[e.cls][e.oct] += 1;
+            if (e.sca >= 0 && e.sca < SA_MAX_SCA) { c->prof_blur_ms[e.oct][e.sca] += ms; c->prof_blur_n[e.oct][e.sca] += 1; }
         }
         c->prof_pool.push_back(e.a); c->prof_pool.push_back(e.b);
     }
@@ -460,7 +498,7 @@ extern "C" int sift_amd_profile_enable(sift_amd_ctx* c, unsigned mask) { c->prof
 extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, double* ms, long long* launches, int reset)
 {
     if (cls < 0 || cls >= SIFT_AMD_K_COUNT || octave >= SA_MAX_OCT) { sa_set_error("bad class/octave"); return -1; }
-    hipSetDevice(c->device);
+    SA_ON_DEVICE(c);
     prof_collect(c);
     double t = 0; long long n = 0;
     for (int o = 0; o < SA_MAX_OCT; o++)
@@ -473,9 +511,21 @@ extern "C" int sift_amd_profile_read(sift_amd_ctx* c, int cls, int octave, doubl
     return 0;
 }
 
+extern "C" int sift_amd_profile_read_blur(sift_amd_ctx* c, int octave, int scale, double* ms, long long* launches, int reset)
+{
+    if (octave < 0 || octave >= SA_MAX_OCT || scale < 0 || scale >= SA_MAX_SCA) { sa_set_error("bad octave/scale"); return -1; }
+    SA_ON_DEVICE(c);
+    prof_collect(c);
+    if (ms) *ms = c->prof_blur_ms[octave][scale];
+    if (launches) *launches = c->prof_blur_n[octave][scale];
+    if (reset) { c->prof_blur_ms[octave][scale] = 0; c->prof_blur_n[octave][scale] = 0; }
+    return 0;
+}
+
 // ---------------------------------------------------------------- pipeline --
 
-static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, const float* in, long long s_in,
+// sca: index, within the octave's Gaussian stack, of the image this blur writes
+static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, int sca, const BlurSpec& b, const float* in, long long s_in,
                      float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n,
                      int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, int* cells = nullptr)
 {
@@ -486,9 +536,9 @@ static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, const BlurSpec& b, 
     a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog; a.s_sub = s_sub;
     a.w = c->L.w[o]; a.h = c->L.h[o]; a.batch = n;
     a.radius = b.radius; a.taps = b.taps; a.taps_dev = b.taps_dev;
-    if (c->fused_blur && b.radius >= 1 && b.radius <= SA_MAX_RADIUS_FAST) {
+    if (b.radius >= 1 && b.radius <= SA_MAX_RADIUS_FAST) {
         // the seed launch that also evaluates the oversampling is timed as the oversampling class
-        ProfScope ps(c, st, ovs_w > 0 ? SIFT_AMD_K_OVERSAMPLE : SIFT_AMD_K_BLUR_FUSED, o);
+        ProfScope ps(c, st, ovs_w > 0 ? SIFT_AMD_K_OVERSAMPLE : SIFT_AMD_K_BLUR_FUSED, o, sca);
         sa::launch_blur_fused(st, a);
         return;
     }
@@ -506,7 +556,7 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
     const int ns = L.n_sca;
     // Cell marks let the extrema scan skip regions without any contrast-passing sample.  They
     // are of no use when every discrete extremum has to be listed.
-    const bool mark = !(c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) && c->fused_blur && c->use_cells;
+    const bool mark = !(c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) && c->use_cells;
     if (mark) HIP_TRY(hipMemsetAsync(c->d_cells[0], 0, c->cells_total * sizeof(int), st));
     for (int o = 0; o < L.n_oct; o++) {
         c->cells_valid[o] = mark;
@@ -515,18 +565,18 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
         float* g = c->d_gss[o];
         float* d = c->d_dog[o];
         if (o == 0) {
-            const bool fuse_ovs = c->fused_blur && c->seed.radius >= 1 && c->seed.radius <= SA_MAX_RADIUS_FAST;
+            const bool fuse_ovs = c->seed.radius >= 1 && c->seed.radius <= SA_MAX_RADIUS_FAST;
             if (L.delta[0] < 1.f && fuse_ovs) {
                 // oversampling evaluated inside the seed blur's loads: no oversampled image in memory
-                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n,
+                run_blur(c, st, 0, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n,
                          c->im_w, c->im_h, L.delta[0]);
             } else if (L.delta[0] < 1.f) {
                 { ProfScope ps(c, st, SIFT_AMD_K_OVERSAMPLE, 0);
                   sa::launch_oversample(st, d_images, c->im_w, c->im_h, (long long)c->im_w * c->im_h,
                                         c->d_seed, L.w[0], L.h[0], np, L.delta[0], n); }
-                run_blur(c, st, 0, c->seed, c->d_seed, np, g, sg, nullptr, 0, nullptr, 0, n);
+                run_blur(c, st, 0, 0, c->seed, c->d_seed, np, g, sg, nullptr, 0, nullptr, 0, n);
             } else {
-                run_blur(c, st, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n);
+                run_blur(c, st, 0, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n);
             }
         }
         // octaves o > 0 start from the even samples of image n_spo of the octave below
@@ -544,7 +594,7 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 if (c->step[o][s].radius >= 1 && c->step[o][s].radius <= SA_MAX_RADIUS_FAST) cells = c->d_cells[o];
                 else c->cells_valid[o] = false;
             }
-            run_blur(c, st, o, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d ? d + (s - 1) * np : nullptr, sd, sub, s_sub, n,
+            run_blur(c, st, o, s, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d ? d + (s - 1) * np : nullptr, sd, sub, s_sub, n,
                      0, 0, 0.f, cells);
         }
     }
@@ -610,8 +660,10 @@ static hipStream_t pick_stream(sift_amd_ctx* c, void* stream) { return stream ? 
 static int begin_run(sift_amd_ctx* c, int n, hipStream_t st)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
-    HIP_TRY(hipSetDevice(c->device));
-    c->last_stream = st; c->last_n = n; c->counters_valid = false;
+    // runs of one context share its pool: a run queued on another stream than the previous one
+    // waits for the previous one
+    if (c->last_stream && c->last_stream != st) HIP_TRY(hipStreamSynchronize(c->last_stream));
+    c->last_stream = st; c->last_n = n; c->counters_valid = false; c->overflowed = false;
     return 0;
 }
 
@@ -677,6 +729,7 @@ static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_
 
 extern "C" int sift_amd_scalespace_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
 {
+    SA_ON_DEVICE(c);
     hipStream_t st = pick_stream(c, stream);
     if (begin_run(c, n, st)) return -1;
     return run_graphed(c, d_images, n, st, 0);
@@ -684,6 +737,7 @@ extern "C" int sift_amd_scalespace_device(sift_amd_ctx* c, const float* d_images
 
 extern "C" int sift_amd_detect_device(sift_amd_ctx* c, const float* d_images, int n, void* stream)
 {
+    SA_ON_DEVICE(c);
     hipStream_t st = pick_stream(c, stream);
     if (begin_run(c, n, st)) return -1;
     return run_graphed(c, d_images, n, st, 1);
@@ -692,7 +746,7 @@ extern "C" int sift_amd_detect_device(sift_amd_ctx* c, const float* d_images, in
 extern "C" int sift_amd_detect_host(sift_amd_ctx* c, const float* images, int n)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(c->d_in, images, (size_t)n * c->im_w * c->im_h * sizeof(float),
                            hipMemcpyHostToDevice, c->own_stream));
     return sift_amd_detect_device(c, c->d_in, n, nullptr);
@@ -705,6 +759,7 @@ extern "C" int sift_amd_detect_device_u8(sift_amd_ctx* c, const unsigned char* d
 {
     if (channels != 1 && channels != 3 && channels != 4) { sa_set_error("channels must be 1, 3 or 4 (got %d)", channels); return -1; }
     if (((uintptr_t)d_images & 3) != 0) { sa_set_error("8-bit device images must be 4-byte aligned"); return -1; }
+    SA_ON_DEVICE(c);
     hipStream_t st = pick_stream(c, stream);
     if (begin_run(c, n, st)) return -1;
     sa::launch_ingest_u8(st, d_images, channels, c->d_in, (long long)n * c->im_w * c->im_h);
@@ -716,7 +771,7 @@ extern "C" int sift_amd_detect_host_u8(sift_amd_ctx* c, const unsigned char* ima
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
     if (channels != 1 && channels != 3 && channels != 4) { sa_set_error("channels must be 1, 3 or 4 (got %d)", channels); return -1; }
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     const size_t bytes = (size_t)n * c->im_w * c->im_h * channels;
     if (bytes > c->d_u8_bytes) {
         if (c->d_u8) HIP_TRY(hipFree(c->d_u8));
@@ -731,7 +786,7 @@ extern "C" int sift_amd_detect_host_u8(sift_amd_ctx* c, const unsigned char* ima
 extern "C" int sift_amd_copy_ingested(sift_amd_ctx* c, int n, float* dst)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(dst, c->d_in, (size_t)n * c->im_w * c->im_h * sizeof(float), hipMemcpyDeviceToHost));
@@ -751,18 +806,26 @@ int sa_ctx_image_keys(sift_amd_ctx* c, int img, const void** d_std, const float*
 
 int sa_sync_counters(sift_amd_ctx* c)
 {
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     if (!c->counters_valid) {
         hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
         HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, (size_t)c->batch * SA_CNT_STRIDE * sizeof(int),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         c->counters_valid = true;
+        c->overflowed = false;
+        for (int b = 0; b < c->last_n; b++)
+            if (c->h_counters[b * SA_CNT_STRIDE + SA_CNT_OVERFLOW]) c->overflowed = true;
+    }
+    // every reader of the run's results gets the error, not only the first one: the lists are
+    // truncated until the next run
+    if (c->overflowed) {
         for (int b = 0; b < c->last_n; b++)
             if (c->h_counters[b * SA_CNT_STRIDE + SA_CNT_OVERFLOW]) {
                 sa_set_error("candidate/keypoint list overflow on image %d (capacity %d/%d/%d)", b, c->cap, c->fcap, c->kcap);
-                return -2;
+                break;
             }
+        return -2;
     }
     return 0;
 }
@@ -805,6 +868,126 @@ extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** ou
     HIP_TRY(hipStreamSynchronize(st));
     *out = buf;
     return 0;
+}
+
+extern "C" int sift_amd_gather_keypoints_into(sift_amd_ctx* c, sift_keypoint_std* out, int max_records, int* counts)
+{
+    if (sa_sync_counters(c)) return -1;
+    SA_ON_DEVICE(c);
+    size_t total = 0;
+    for (int b = 0; b < c->last_n; b++) {
+        counts[b] = c->h_counters[b * SA_CNT_STRIDE + SA_CNT_KEYS];
+        total += counts[b];
+    }
+    if (total > (size_t)max_records) {
+        sa_set_error("gather buffer holds %d records, the batch has %zu", max_records, total);
+        return -1;
+    }
+    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    const SaStd* src = c->last_n > 1 ? c->d_packed : c->d_std;
+    if (total) HIP_TRY(hipMemcpyAsync(out, src, total * sizeof(SaStd), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return (int)total;
+}
+
+// ---------------------------------------------------------- copy ceiling --
+// What a read-one-write-one stream reaches on this GPU: every block copies one contiguous
+// range with eight 16-byte loads in flight per thread, nontemporal accesses (the fastest of
+// the forms tried: grid-stride or block-contiguous, 1..8 loads in flight, plain or nontemporal).
+typedef float sa_v4f __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_copy_ceiling(const sa_v4f* __restrict__ in, sa_v4f* __restrict__ out, size_t n)
+{
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n ? b0 + per : n;
+    size_t i = b0 + threadIdx.x;
+    for (; i + 7 * 256 < b1; i += 8 * 256) {
+        sa_v4f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&in[i + u * 256]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) __builtin_nontemporal_store(v[u], &out[i + u * 256]);
+    }
+    for (; i < b1; i += 256) out[i] = in[i];
+}
+
+// The rate at which this GPU executes plain (non-fused) float32 multiplies and adds when
+// nothing else limits them: every thread runs 16 independent mul+add chains from registers.
+// The blur's arithmetic is of this kind (each product and each sum rounded separately, as the
+// reference prescribes), so this is the arithmetic ceiling its large radii run against.
+__global__ void __launch_bounds__(256) k_valu_ceiling(float* out, int iters, float a, float b)
+{
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = (float)(threadIdx.x + k);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = __fadd_rn(__fmul_rn(acc[k], a), b);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += acc[k];
+    if (s == 12345.678f) out[0] = s;
+}
+
+extern "C" int sift_amd_valu_ceiling(int device, int reps, double* lane_gops)
+{
+    DeviceGuard dev_guard_(device);
+    if (!dev_guard_.ok) return -1;
+    float* d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    float ms = 0.f;
+    const int iters = 4096, blocks = 256 * 16;     // 16 waves per SIMD in total, 4 resident at a time
+    do {
+        if (hipMalloc((void**)&d, 256) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters, 0.999f, 0.001f);
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        (void)hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters, 0.999f, 0.001f);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+        *lane_gops = (double)blocks * 256 * iters * 32.0 * reps / (ms * 1e-3) / 1e9;
+        rc = 0;
+    } while (0);
+    if (rc) sa_set_error("valu ceiling: %s", hipGetErrorString(hipGetLastError()));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (d) (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int sift_amd_copy_ceiling(int device, size_t bytes, int reps, double* gb_per_s)
+{
+    DeviceGuard dev_guard_(device);
+    if (!dev_guard_.ok) return -1;
+    if (bytes < (1u << 20) || reps < 1) { sa_set_error("copy ceiling: need >= 1 MiB and >= 1 repetition"); return -1; }
+    const size_t n = bytes / 16;
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    float ms = 0.f;
+    do {
+        if (hipMalloc(&a, n * 16) != hipSuccess || hipMalloc(&b, n * 16) != hipSuccess) { sa_set_error("copy ceiling: hipMalloc failed"); break; }
+        if (hipMemset(a, 1, n * 16) != hipSuccess || hipMemset(b, 0, n * 16) != hipSuccess) break;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+        hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, nullptr, (const sa_v4f*)a, (sa_v4f*)b, n);
+        if (hipDeviceSynchronize() != hipSuccess) break;
+        (void)hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps; ++r)
+            hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, nullptr, (const sa_v4f*)a, (sa_v4f*)b, n);
+        (void)hipEventRecord(e1, nullptr);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+        *gb_per_s = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
+        rc = 0;
+    } while (0);
+    if (rc && !sift_amd_last_error()[0]) sa_set_error("copy ceiling: %s", hipGetErrorString(hipGetLastError()));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
 }
 
 extern "C" int sift_amd_stage_counts(sift_amd_ctx* c, int img, int stage_sizes[6], int ext_oct[SIFT_AMD_MAX_OCT])
@@ -870,7 +1053,7 @@ extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int
         sa_set_error("DoG images are only stored in a context created with SIFT_AMD_KEEP_SCALESPACE");
         return -1;
     }
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
     HIP_TRY(hipStreamSynchronize(st));
     const long long np = (long long)c->L.w[o] * c->L.h[o];
@@ -927,9 +1110,9 @@ extern "C" int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* c, int img, float
 int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orientation)
 {
     if (n > c->fcap) { sa_set_error("too many keypoints (%d > %d)", n, c->fcap); return -1; }
-    HIP_TRY(hipSetDevice(c->device));
+    SA_ON_DEVICE(c);
     hipStream_t st = c->own_stream;
-    c->last_stream = st; c->last_n = 1; c->counters_valid = false;
+    c->last_stream = st; c->last_n = 1; c->counters_valid = false; c->overflowed = false;
     int cnt[SA_CNT_STRIDE] = {0};
     cnt[SA_CNT_NF] = n; cnt[SA_CNT_KEYS] = n;
     HIP_TRY(hipStreamSynchronize(st));
@@ -943,6 +1126,15 @@ int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orien
     if (sa_run_describe(c, 1, st)) return -1;
     HIP_TRY(hipStreamSynchronize(st));
     return 0;
+}
+
+// largest number of candidates the extrema scan met on one image of the last run (it counts
+// also those that found no room in the list)
+int sa_ctx_candidates_seen(const sift_amd_ctx* c)
+{
+    int m = 0;
+    for (int b = 0; b < c->last_n; b++) m = std::max(m, c->h_counters[b * SA_CNT_STRIDE + SA_CNT_CAND]);
+    return m;
 }
 
 int sa_ctx_limits(const sift_amd_ctx* c, int* cap, int* fcap, int* kcap)

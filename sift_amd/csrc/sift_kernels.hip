@@ -197,139 +197,21 @@ k_subsample2(const float* __restrict__ in, int wi, long long s_in,
 }
 
 // ------------------------------------------------------------ Gaussian blur --
-// lib_discrete.c:278-308: pass 1 along i (column direction) into a temporary, pass 2 along
-// j.  Per output:  sum = centre*g0;  sum += g[k]*(left_k + right_k)  for k = 1..R.
-
-// Pass 1.  One thread per column; it walks down a strip of rows keeping the 2R+G most
-// recent samples in registers, so every input sample is loaded once per strip and lanes of
-// a wave read consecutive addresses.  No LDS.
-template <int R>
-__global__ void __launch_bounds__(256)
-k_blur_v(const float* __restrict__ in, float* __restrict__ out, int w, int h,
-         long long s_in, long long s_out, SaTaps tp, int rows_per_block)
-{
-    constexpr int G = 8;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= w) return;
-    const float* src = in + (long long)blockIdx.z * s_in + j;
-    float* dst = out + (long long)blockIdx.z * s_out + j;
-    const int i0 = blockIdx.y * rows_per_block;
-    const int i1 = min(i0 + rows_per_block, h);
-
-    float win[G + 2 * R];
-    float nx[G];
-#pragma unroll
-    for (int t = 0; t < 2 * R; ++t) win[t] = src[(long long)mirror_idx(i0 - R + t, h) * w];
-#pragma unroll
-    for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(i0 + R + g, h) * w];
-
-    for (int ii = i0; ii < i1; ii += G) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) win[2 * R + g] = nx[g];
-        if (ii + G < i1) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) nx[g] = src[(long long)mirror_idx(ii + G + R + g, h) * w];
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float s = __fmul_rn(win[g + R], tp.g[0]);
-#pragma unroll
-            for (int k = 1; k <= R; ++k)
-                s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[g + R - k], win[g + R + k])));
-            if (ii + g < i1) dst[(long long)(ii + g) * w] = s;
-        }
-#pragma unroll
-        for (int t = 0; t < 2 * R; ++t) win[t] = win[t + G];
-    }
-}
-
-// Pass 2 with the DoG epilogue.  A wave stages one row segment of 256+2*16 samples in
-// LDS, every lane then produces 4 adjacent outputs from a 36-sample register window
-// (9 aligned 16-byte LDS reads).  Writes gss[s] and, if `dog` is given,
-// dog[s-1] = gss[s] - gss[s-1]  (lib_sift_anatomy.c:169-186).
-template <int R>
-__global__ void __launch_bounds__(256)
-k_blur_h(const float* __restrict__ tmp, const float* __restrict__ prev,
-         float* __restrict__ out, float* __restrict__ dog, int w, int h,
-         long long s_tmp, long long s_prev, long long s_out, long long s_dog,
-         SaTaps tp, int rows_per_wave)
-{
-    constexpr int RP = 16, TW = 256, LW = TW + 2 * RP;
-    __shared__ __attribute__((aligned(16))) float lds[4][LW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int x0 = blockIdx.x * TW;
-    const int row0 = (blockIdx.y * 4 + wave) * rows_per_wave;
-    const long long b = blockIdx.z;
-    const float* src = tmp + b * s_tmp;
-    const bool fast = ((w & 3) == 0) && (x0 - RP >= 0) && (x0 + TW + RP <= w);
-    float* row_lds = lds[wave];
-
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int row = row0 + rr;
-        const bool active = row < h;
-        if (active) {
-            const float* srow = src + (long long)row * w;
-            if (fast) {
-                const v4f a = ld4(srow + x0 - RP + 4 * lane);
-                *reinterpret_cast<v4f*>(row_lds + 4 * lane) = a;
-                if (lane < (LW - TW) / 4) {
-                    const v4f c = ld4(srow + x0 - RP + TW + 4 * lane);
-                    *reinterpret_cast<v4f*>(row_lds + TW + 4 * lane) = c;
-                }
-            } else {
-                for (int t = lane; t < LW; t += 64) row_lds[t] = srow[mirror_idx(x0 - RP + t, w)];
-            }
-        }
-        __syncthreads();
-        if (active) {
-            float win[4 + 2 * RP];
-#pragma unroll
-            for (int q = 0; q < (4 + 2 * RP) / 4; ++q) {
-                const v4f v = ld4(row_lds + 4 * lane + 4 * q);
-                win[4 * q + 0] = v.x; win[4 * q + 1] = v.y; win[4 * q + 2] = v.z; win[4 * q + 3] = v.w;
-            }
-            float o4[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s = __fmul_rn(win[RP + q], tp.g[0]);
-#pragma unroll
-                for (int k = 1; k <= R; ++k)
-                    s = __fadd_rn(s, __fmul_rn(tp.g[k], __fadd_rn(win[RP + q - k], win[RP + q + k])));
-                o4[q] = s;
-            }
-            const int x = x0 + 4 * lane;
-            const long long off = (long long)row * w + x;
-            if (fast) {
-                st4(out + b * s_out + off, o4[0], o4[1], o4[2], o4[3]);
-                if (dog) {
-                    const v4f p = ld4(prev + b * s_prev + off);
-                    st4(dog + b * s_dog + off, __fsub_rn(o4[0], p.x), __fsub_rn(o4[1], p.y),
-                        __fsub_rn(o4[2], p.z), __fsub_rn(o4[3], p.w));
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (x + q < w) {
-                        out[b * s_out + off + q] = o4[q];
-                        if (dog) dog[b * s_dog + off + q] = __fsub_rn(o4[q], prev[b * s_prev + off + q]);
-                    }
-            }
-        }
-        __syncthreads();
-    }
-}
+// lib_discrete.c:278-308: pass 1 along i (column direction), pass 2 along j.
+// Per output:  sum = centre*g0;  sum += g[k]*(left_k + right_k)  for k = 1..R.
 
 // Both passes in one kernel.  A block owns 224 output columns (256 with the 16-column halo on
 // each side) and walks down a strip of rows, 8 rows per iteration:
-//   - column pass as in k_blur_v: thread t keeps the 2R+8 newest samples of extended column t
-//     in registers and produces 8 column-filtered samples, which go to LDS together with the
-//     8 unfiltered centre samples (needed for the DoG);
+//   - column pass: thread t keeps the 2R+8 newest samples of extended column t in registers (every
+//     source sample is loaded once per strip, lanes of a wave read consecutive addresses) and
+//     produces 8 column-filtered samples, which go to LDS together with the 8 unfiltered centre
+//     samples (needed for the DoG);
 //   - row pass: thread (row g, group q) reads 36 consecutive column-filtered samples of row g
 //     from LDS and produces 4 adjacent outputs, stored with 16-byte accesses (448 such items
 //     per iteration, two per thread).
 // Per pixel the kernel reads the source image once (plus the strip/tile halo, served by L2)
 // and writes gss[s] and dog[s-1]; the column-pass image never exists in memory.  Operation
-// order per output is identical to the two-kernel form, so results are bit-identical.
+// order per output is that of the reference's two passes, so results are bit-identical.
 // `flags`, if given, gets a mark per 8-row x 64-column cell of the image in which some DoG
 // sample exceeds flag_thr in magnitude (cells [image][row/8][col/64]); the extrema scan skips
 // unmarked cells.
@@ -1232,186 +1114,18 @@ k_expand(const SaKey* __restrict__ keys, const int* __restrict__ index, int* __r
 
 // ------------------------------------------------------------- descriptor --
 // lib_description.c:278-347 (accumulation) and :374-389 (clip, renormalise, quantise),
-// driver loop lib_sift_anatomy.c:724-765.  One block of BS threads per keypoint.
+// driver loop lib_sift_anatomy.c:724-765.
 //
 // The reference adds every sample's (up to 2x2 cells) x (2 orientation bins) contributions
-// into float bins in raster order of the samples.  To get the same bits without serialising
-// everything, the patch is swept in raster order BS samples at a time:
-//   A. every thread evaluates one sample (rotation, gradient, Gaussian weight, the two
-//      double-precision contributions per touched cell);
-//   B. the contributions are appended to per-cell lists in LDS, in sample order (wave ballots
-//      give each sample its rank inside the wave, LDS counters the offsets between waves);
-//   C. thread t < n_descr, which owns descriptor bin t = (cell, k), walks its cell's list in
-//      order and adds the entries that fall into orientation bin k.
-// A bin receives at most one contribution per sample, so list order = reference order.
+// into float bins in raster order of the samples.  A bin receives at most one contribution per
+// sample, so keeping the contributions of a bin in sample order and adding them one after the
+// other gives the reference's bits without serialising the whole patch.
 #define SA_MAX_CELLS 64
-template <int BS>
-__global__ void __launch_bounds__(BS)
-k_descriptor(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ counters,
-             int cnt_slot, int kcap, SaStd* __restrict__ out_std, float* __restrict__ out_descr)
-{
-    constexpr int NW = BS / 64, POOL = 4 * BS;
-    __shared__ double p_cL[POOL], p_cR[POOL];
-    __shared__ int p_k[POOL];
-    __shared__ int wcount[NW][SA_MAX_CELLS];
-    __shared__ int cstart[SA_MAX_CELLS + 1];
-    __shared__ float d_s[SA_MAX_DESCR];
-    __shared__ float norm_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long b = blockIdx.y;
-    const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
-    const int Nh = sc.n_hist, Nb = sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
-    const int my_cell = tid / Nb, bk = tid % Nb;
-    const unsigned long long lt = lanemask_lt();
-    for (int q = blockIdx.x; q < n; q += gridDim.x) {
-        const SaKey key = keys[b * kcap + q];
-        const SaOctave& oc = P.oct[key.o];
-        const int w = oc.w, h = oc.h;
-        const float* im = oc.gss + b * oc.gss_stride + (long long)key.s * w * h;
-        const float xk = __fdiv_rn(key.x, oc.delta), yk = __fdiv_rn(key.y, oc.delta);
-        const float sk = __fdiv_rn(key.sigma, oc.delta);
-        const float theta = key.theta;
-        const float R = __fmul_rn(__fmul_rn(__fadd_rn(1.f, __fdiv_rn(1.f, (float)Nh)), sc.lambda_descr), sk);
-        const float Rp = (float)(SA_SQRT2 * (double)R);
-        const int i0 = max(0, (int)((double)__fsub_rn(xk, Rp) + 0.5));
-        const int j0 = max(0, (int)((double)__fsub_rn(yk, Rp) + 0.5));
-        const int i1 = min((int)((double)__fadd_rn(xk, Rp) + 0.5), h - 1);
-        const int j1 = min((int)((double)__fadd_rn(yk, Rp) + 0.5), w - 1);
-        const int nw = j1 - j0, nh = i1 - i0;                 // upper bounds are exclusive
-        const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
-        const float ma = -theta;
-        const float ct = (float)cos((double)ma), st = (float)sin((double)ma);
-        const double tt = (double)__fmul_rn(sc.lambda_descr, sk);
-        const double two_t2 = 2 * tt * tt;
-        const float cell = __fdiv_rn(__fmul_rn(__fmul_rn(2.f, sc.lambda_descr), sk), (float)Nh);
-        const double half = ((double)Nh - 1.0) / 2.0;
-        float acc = 0.f;
-        for (int p0 = 0; p0 < npix; p0 += BS) {
-            // ---- A: one sample per thread
-            const int p = p0 + tid;
-            bool inside = false;
-            int a0 = 0, b0 = 0, k0 = 0;
-            double cL[4], cR[4];
-            if (p < npix) {
-                const int si = i0 + p / nw, sj = j0 + p % nw;
-                const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
-                const float X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
-                const float Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
-                if (fmaxf(fabsf(X), fabsf(Y)) < R) {
-                    inside = true;
-                    const double dx = (double)grad_i(im, w, h, si, sj);
-                    const double dy = (double)grad_j(im, w, h, si, sj);
-                    float ori = (float)(atan2(dy, dx) - (double)theta);
-                    ori = modulus_f(ori, (float)(2 * SA_PI));
-                    const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
-                    const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
-                    const float al = (float)((double)__fdiv_rn(X, cell) + half);
-                    const float be = (float)((double)__fdiv_rn(Y, cell) + half);
-                    const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
-                    a0 = (int)floor((double)al);
-                    b0 = (int)floor((double)be);
-                    const double gf = floor((double)ga);
-                    k0 = wrap_bin((int)ga, Nb);
-                    const double wl = 1. - ((double)ga - gf);
-                    const double wr = 1.0 - (gf + 1 - (double)ga);
-#pragma unroll
-                    for (int sl = 0; sl < 4; ++sl) {
-                        const float da = fabsf(__fsub_rn((float)(a0 + (sl >> 1)), al));
-                        const float db = fabsf(__fsub_rn((float)(b0 + (sl & 1)), be));
-                        const double wa = 1.0 - (double)da, wb = 1.0 - (double)db;
-                        cL[sl] = wl * wa * wb * M;
-                        cR[sl] = wr * wa * wb * M;
-                    }
-                }
-            }
-            // ---- B: ordered append to the per-cell lists
-            int rank[4] = {0, 0, 0, 0};
-            for (int c = 0; c < ncell; ++c) {
-                const int di = c / Nh - a0, dj = c % Nh - b0;
-                const bool f = inside && (unsigned)di < 2u && (unsigned)dj < 2u;
-                const unsigned long long m = __ballot(f);
-                if (lane == 0) wcount[wave][c] = __popcll(m);
-                if (f) {
-                    const int r = __popcll(m & lt), sl = di * 2 + dj;
-                    if (sl == 0) rank[0] = r; else if (sl == 1) rank[1] = r;
-                    else if (sl == 2) rank[2] = r; else rank[3] = r;
-                }
-            }
-            __syncthreads();
-            if (wave == 0) {
-                int tot = 0;
-                if (lane < ncell)
-                    for (int v = 0; v < NW; ++v) tot += wcount[v][lane];
-                int inc = tot;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int t = __shfl_up(inc, d);
-                    if (lane >= d) inc += t;
-                }
-                if (lane < ncell) cstart[lane] = inc - tot;
-                if (lane == ncell - 1) cstart[ncell] = inc;
-            }
-            __syncthreads();
-            if (inside) {
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    const int ci = a0 + (sl >> 1), cj = b0 + (sl & 1);
-                    if ((unsigned)ci < (unsigned)Nh && (unsigned)cj < (unsigned)Nh) {
-                        const int c = ci * Nh + cj;
-                        int pos = cstart[c] + rank[sl];
-                        for (int v = 0; v < wave; ++v) pos += wcount[v][c];
-                        p_k[pos] = k0; p_cL[pos] = cL[sl]; p_cR[pos] = cR[sl];
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- C: bin owners consume their cell's list in order
-            if (tid < nd) {
-                const int e1 = cstart[my_cell + 1];
-                const int k1 = bk == 0 ? Nb - 1 : bk - 1;      // bin whose right neighbour is bk
-                for (int e = cstart[my_cell]; e < e1; ++e) {
-                    const int kk = p_k[e];
-                    if (kk == bk) acc = (float)((double)acc + p_cL[e]);
-                    else if (kk == k1) acc = (float)((double)acc + p_cR[e]);
-                }
-            }
-            __syncthreads();
-        }
-        if (tid < nd) d_s[tid] = acc;
-        __syncthreads();
-        // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
-        if (tid == 0) {
-            float l2 = 0.f;
-            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
-            norm_s = (float)sqrt((double)l2);
-        }
-        __syncthreads();
-        if (tid < nd) d_s[tid] = fminf(acc, __fmul_rn(0.2f, norm_s));
-        __syncthreads();
-        if (tid == 0) {
-            float l2 = 0.f;
-            for (int k = 0; k < nd; ++k) l2 = __fadd_rn(l2, __fmul_rn(d_s[k], d_s[k]));
-            norm_s = (float)sqrt((double)l2);
-        }
-        __syncthreads();
-        if (tid < nd) {
-            float v = (float)(int)((double)d_s[tid] * 512.0 / (double)norm_s);
-            v = v < 255.f ? v : 255.f;
-            if (out_descr) out_descr[(b * kcap + q) * SA_MAX_DESCR + tid] = v;
-            if (out_std && tid < 128) out_std[b * kcap + q].descriptor[tid] = (unsigned char)v;
-        }
-        if (out_std && tid == 0) {
-            SaStd* o = &out_std[b * kcap + q];
-            o->x = key.x; o->y = key.y; o->scale = key.sigma; o->orientation = key.theta;
-        }
-        __syncthreads();
-    }
-}
 
-// Wave-per-keypoint form of the descriptor kernel (the default).  Same arithmetic and the same
-// per-bin order of additions as k_descriptor above, but one 64-lane wave owns a keypoint, so no
-// block-wide barriers are needed, and the samples that fall inside the rotated window are first
-// queued (in raster order) so that the expensive double-precision part always runs on full
-// waves.  Lane l owns the BPL consecutive descriptor bins l*BPL .. l*BPL+BPL-1.
+// One 64-lane wave owns a keypoint, so no block-wide barriers are needed, and the samples that
+// fall inside the rotated window are first queued (in raster order) so that the expensive
+// double-precision part always runs on full waves.  Lane l owns the BPL consecutive descriptor
+// bins l*BPL .. l*BPL+BPL-1.
 // array_l2norm (lib_util.c:156-164) over LDS by one lane: sequential float sum, four values
 // per LDS read.
 __device__ __forceinline__ float seq_l2norm(const float* d, int n)
@@ -1792,6 +1506,10 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 if (out_std && t < 128) out_std[b * kcap + q].descriptor[t] = (unsigned char)v;
             }
         }
+        // the 144-byte record has room for 128 bins: shorter descriptors are zero-padded, longer
+        // ones are cut there (the float descriptors hold every bin)
+        if (out_std && nd < 128)
+            for (int t = nd + lane; t < 128; t += 64) out_std[b * kcap + q].descriptor[t] = 0;
         if (out_std && lane == 0) {
             SaStd* o = &out_std[b * kcap + q];
             o->x = key.x; o->y = key.y; o->scale = key.sigma; o->orientation = key.theta;
@@ -1816,18 +1534,6 @@ k_descriptor_wave(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, con
 {
     descriptor_wave_body<BPL>(P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
 }
-
-// Same kernel compiled for a given number of resident waves per SIMD (register budget).
-#define SA_DESCR_WPE(N)                                                                                          \
-    __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(N, N)))                             \
-    k_descriptor_wave2_wpe##N(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys,                         \
-                              const int* __restrict__ counters, int cnt_slot, int kcap,                          \
-                              SaStd* __restrict__ out_std, float* __restrict__ out_descr)                        \
-    {                                                                                                            \
-        descriptor_wave_body<2>(P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);                      \
-    }
-SA_DESCR_WPE(4)
-SA_DESCR_WPE(5)
 
 // The default 4 x 4 x 8 shape.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
@@ -1859,22 +1565,6 @@ k_pack_std(const SaStd* __restrict__ std_recs, const int* __restrict__ counters,
 #define HIPK(...) do { hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 namespace sa {
-
-template <int R>
-static void blur_v_t(hipStream_t st, const BlurArgs& a)
-{
-    const int rows = 64;
-    dim3 grid((a.w + 255) / 256, (a.h + rows - 1) / rows, a.batch);
-    HIPK(k_blur_v<R>, grid, dim3(256), 0, st, a.in, a.tmp, a.w, a.h, a.s_in, a.s_tmp, a.taps, rows);
-}
-template <int R>
-static void blur_h_t(hipStream_t st, const BlurArgs& a)
-{
-    const int rpw = 8;
-    dim3 grid((a.w + 255) / 256, (a.h + 4 * rpw - 1) / (4 * rpw), a.batch);
-    HIPK(k_blur_h<R>, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
-         a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps, rpw);
-}
 
 #define SA_R_CASES(F) \
     case 1: F(1); break; case 2: F(2); break; case 3: F(3); break; case 4: F(4); break; \
@@ -1938,31 +1628,16 @@ bool launch_blur_fused(hipStream_t st, const BlurArgs& a)
     return true;
 }
 
-// pass 0: column pass (in -> tmp); pass 1: row pass (tmp -> out [, dog = out - in]).
+// Any-radius form, two launches.  pass 0: column pass (in -> tmp); pass 1: row pass (tmp -> out
+// [, dog = out - in]).
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass)
 {
-    if (a.radius >= 1 && a.radius <= SA_MAX_RADIUS_FAST) {
-        if (pass == 0) {
-            switch (a.radius) {
-#define F(R) blur_v_t<R>(st, a)
-                SA_R_CASES(F)
-#undef F
-            }
-        } else {
-            switch (a.radius) {
-#define F(R) blur_h_t<R>(st, a)
-                SA_R_CASES(F)
-#undef F
-            }
-        }
-    } else {
-        dim3 grid((a.w + 255) / 256, a.h, a.batch);
-        if (pass == 0)
-            HIPK(k_blur_v_any, grid, dim3(256), 0, st, a.in, a.tmp, a.w, a.h, a.s_in, a.s_tmp, a.taps_dev, a.radius);
-        else
-            HIPK(k_blur_h_any, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
-                 a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps_dev, a.radius);
-    }
+    dim3 grid((a.w + 255) / 256, a.h, a.batch);
+    if (pass == 0)
+        HIPK(k_blur_v_any, grid, dim3(256), 0, st, a.in, a.tmp, a.w, a.h, a.s_in, a.s_tmp, a.taps_dev, a.radius);
+    else
+        HIPK(k_blur_h_any, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
+             a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps_dev, a.radius);
 }
 
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
@@ -2060,34 +1735,21 @@ void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, 
                        const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
                        int batch)
 {
-    static const bool block_form = getenv("SIFT_AMD_DESCR") && !strcmp(getenv("SIFT_AMD_DESCR"), "block");
     const int nd = sc.n_hist * sc.n_hist * sc.n_ori;
-    if (!block_form) {
-        // one wave per keypoint, further keypoints of an image in a grid-stride loop; most images
-        // have fewer keypoints than this and empty blocks are not free to dispatch
-        const dim3 grid(1024, batch), blk(64);
-        switch ((nd + 63) / 64) {
-            case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
-            case 2: {
-                static const int wpe = getenv("SIFT_AMD_DESCR_WPE") ? atoi(getenv("SIFT_AMD_DESCR_WPE")) : 4;
-                if (wpe == 4 && sc.n_hist == 4 && sc.n_ori == 8 && !sc.debug)
-                    HIPK(k_descriptor_wave_448, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
-                else if (wpe == 4) HIPK(k_descriptor_wave2_wpe4, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
-                else if (wpe == 5) HIPK(k_descriptor_wave2_wpe5, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
-                else HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
-                break;
-            }
-            case 3: HIPK(k_descriptor_wave<3>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
-            default: HIPK(k_descriptor_wave<4>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
-        }
-        return;
+    // one wave per keypoint, further keypoints of an image in a grid-stride loop; most images
+    // have fewer keypoints than this and empty blocks are not free to dispatch
+    const dim3 grid(1024, batch), blk(64);
+    switch ((nd + 63) / 64) {
+        case 1: HIPK(k_descriptor_wave<1>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+        case 2:
+            if (sc.n_hist == 4 && sc.n_ori == 8 && !sc.debug)
+                HIPK(k_descriptor_wave_448, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+            else
+                HIPK(k_descriptor_wave<2>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr);
+            break;
+        case 3: HIPK(k_descriptor_wave<3>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
+        default: HIPK(k_descriptor_wave<4>, grid, blk, 0, st, P, sc, keys, counters, cnt_slot, kcap, out_std, out_descr); break;
     }
-    if (sc.n_hist * sc.n_hist * sc.n_ori <= 128)
-        HIPK(k_descriptor<128>, dim3(2048, batch), dim3(128), 0, st, P, sc, keys, counters, cnt_slot, kcap,
-             out_std, out_descr);
-    else
-        HIPK(k_descriptor<256>, dim3(1024, batch), dim3(256), 0, st, P, sc, keys, counters, cnt_slot, kcap,
-             out_std, out_descr);
 }
 
 void launch_pack_std(hipStream_t st, const SaStd* std_recs, const int* counters, int cnt_slot, int kcap,

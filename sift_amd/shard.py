@@ -34,3 +34,31 @@ def gather_keypoints(local, dist=None, dst=0):
     flat = [t for part in bucket for t in part]
     flat.sort(key=lambda t: t[0])
     return [np.frombuffer(b, dtype=np.dtype([tuple(f) for f in d])).copy() for _, b, d in flat]
+
+
+def launch_plan(begin, end, batch):
+    """Cuts the images [begin, end) of a fixed batch into launches of at most `batch` images that
+    never straddle a multiple of `batch` (a launch reads a contiguous piece of a pool of `batch`
+    resident images, image g being pool image g % batch).  Returns [(first image, count)]."""
+    if batch < 1 or end < begin:
+        raise ValueError("bad range/batch")
+    plan, g = [], begin
+    while g < end:
+        n = min(batch - g % batch, end - g)
+        plan.append((g, n))
+        g += n
+    return plan
+
+
+def gather_counts(begin, counts, dist=None, dst=0):
+    """Per-image integer results of contiguous shards -> one array in image order on rank `dst`
+    (None elsewhere)."""
+    counts = np.asarray(counts, np.int64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return counts
+    bucket = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object((int(begin), counts.tobytes()), bucket, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    bucket.sort(key=lambda t: t[0])
+    return np.concatenate([np.frombuffer(b, np.int64) for _, b in bucket])

@@ -32,6 +32,10 @@ CASES = [
     ("white_333x257_spo4", "white", 333, 257, 5, {"n_spo": 4}, True),
     ("white_160x120_delta1", "white", 160, 120, 6, {"delta_min": 1.0}, True),
     ("smooth_800x640", "smooth", 800, 640, 12345, {}, True),
+    # stand-ins for photographs (the Oxford images are not available offline): edges, corners and
+    # texture at many scales, so that the edge filter and all octaves are exercised
+    ("natural_800x640_a", "natural", 800, 640, 1, {}, True),
+    ("natural_800x640_b", "natural", 800, 640, 2, {}, True),
     ("smooth_1920x1080", "smooth", 1920, 1080, 12345, {}, False),
     ("white_1920x1080", "white", 1920, 1080, 12345, {}, False),
     ("smooth_3840x2160", "smooth", 3840, 2160, 12345, {}, False),

@@ -94,15 +94,31 @@ def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
     cos = glob.glob(so + ".*gfx950*")
     assert cos, "no gfx950 code object in the library"
     asm = "".join(subprocess.check_output([objdump, "-d", co]).decode() for co in cos)
-    current, bad, seen = None, {}, set()
+    # every kernel whose float arithmetic decides discrete extrema or refined positions
+    families = ["k_blur_fused", "k_blur_v_any", "k_blur_h_any", "k_oversample", "k_subsample2", "k_sub",
+                "k_gradient", "k_extrema", "k_refine"]
+    pat = re.compile("|".join(families))
+    current, fused, divs, seen = None, {}, {}, set()
     for line in asm.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
             current = m.group(1)
             continue
-        if current and re.search(r"k_blur_[vh]|k_oversample|k_sub", current):
+        if current and pat.search(current):
             seen.add(current)
-            if re.search(r"\bv_(fma|fmac|mad|mac|pk_fma)_f32", line):
-                bad[current] = bad.get(current, 0) + 1
-    assert len(seen) >= 30, f"blur kernels not found in the disassembly ({len(seen)})"
+            if re.search(r"\bv_div_fmas_f32", line):
+                divs[current] = divs.get(current, 0) + 1
+            elif re.search(r"\bv_fmamk_f32 .*0x[4c]f800000", line):
+                pass      # 2^32 scaling inside the 64-bit integer division helper, no image data
+            elif re.search(r"\bv_(fma|fmac|mad|mac|pk_fma|fmaak|fmamk|madak|madmk)_f32", line):
+                fused[current] = fused.get(current, 0) + 1
+    # a correctly rounded float division (__fdiv_rn, as the reference's `/`) expands to
+    # v_div_scale/v_rcp, five fused steps, v_div_fmas, v_div_fixup: those five are the only
+    # fused multiply-adds allowed
+    bad = {k: (n, divs.get(k, 0)) for k, n in fused.items() if n != 5 * divs.get(k, 0)}
+    for fam in families:
+        assert any(re.search(fam + r"(?![a-z_0-9]*_any)" if fam == "k_sub" else fam, k) for k in seen), \
+            f"{fam} not found in the disassembly"
+    n_fused = sum("k_blur_fused" in k for k in seen)
+    assert n_fused >= 64, f"only {n_fused} k_blur_fused instantiations in the disassembly"
     assert not bad, f"fused multiply-adds in bit-exact kernels: {bad}"

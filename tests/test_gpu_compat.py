@@ -248,3 +248,57 @@ def test_concurrent_host_threads(hip):
         th.join()
     assert not errors, errors
     assert len(want[0][0]) > 144 * 20
+
+
+def test_reference_named_calls_grow_their_lists_instead_of_aborting(hip, monkeypatch):
+    """The reference's lists grow as needed.  With the default list capacities forced far too
+    small, sift_anatomy(), sift_compute_features() and sift_compute_points() repeat the run with
+    lists sized from the first run's counters and return the reference's result."""
+    w, h = 200, 150
+    img = synth.white(w, h, 31)
+    want = pyoracle.run(img, keep_ss=False)
+    monkeypatch.setenv("SIFT_AMD_CAP", "64")
+    hip.sift_amd_release_thread_cache()
+    with sift_amd.Context(w, h) as ctx:                     # the forced capacity does overflow
+        ctx.detect_host(img)
+        with pytest.raises(api.SiftAmdError):
+            ctx.counts()
+    got = refrun.run_sift_anatomy(hip, img, keep_ss=False)
+    for name in "ABCDEF":
+        assert np.array_equal(got["stages"][name]["ints"], want["stages"][name]["ints"]), name
+    assert np.array_equal(got["keys"]["descr"], want["keys"]["descr"])
+    assert same_bits(np.ascontiguousarray(got["keys"]["flts"][:, :4]), np.ascontiguousarray(want["keys"]["flts"][:, :4]))
+    flat = api.sift_compute_features(img)
+    assert np.array_equal(flat["descriptor"], want["keys"]["descr"].astype(np.uint8))
+    n = C.c_int()
+    p = hip.sift_compute_points(img.ctypes.data_as(abi.c_float_p), w, h, C.byref(n))
+    C.CDLL(None).free(C.cast(p, C.c_void_p))
+    assert n.value == len(want["stages"]["F"]["ints"])
+    hip.sift_amd_release_thread_cache()
+
+
+def test_alternating_reference_named_calls_keep_their_contexts(hip):
+    """sift_anatomy, the flat API and scalespace_compute at one image size, in turn: each keeps
+    its cached context (results stay right, and the second round is much faster than the first
+    because no pool is rebuilt)."""
+    import time
+    w, h = 320, 240
+    img = synth.white(w, h, 77)
+    want = pyoracle.run(img, keep_ss=True)
+    hip.sift_amd_release_thread_cache()
+    times = []
+    for rnd in range(3):
+        t0 = time.perf_counter()
+        got = refrun.run_sift_anatomy(hip, img, keep_ss=False)
+        flat = api.sift_compute_features(img)
+        ss = hip.sift_malloc_scalespace_lowe(len(want["octaves"]), 3, w, h, C.c_float(0.5), C.c_float(0.8))
+        hip.scalespace_compute(ss, img.ctypes.data_as(abi.c_float_p), w, h, C.c_float(0.5))
+        gss = abi.scalespace_to_numpy(ss)
+        hip.sift_free_scalespace(ss)
+        times.append(time.perf_counter() - t0)
+        assert np.array_equal(got["keys"]["descr"], want["keys"]["descr"])
+        assert np.array_equal(flat["descriptor"], want["keys"]["descr"].astype(np.uint8))
+        for o in range(len(gss)):
+            assert same_bits(gss[o]["stack"], want["gss"][o])
+    print("rounds:", times)
+    hip.sift_amd_release_thread_cache()

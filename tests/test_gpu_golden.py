@@ -64,3 +64,36 @@ def test_hip_reproduces_golden(hip, name):
         exact_descr = digest(np.ascontiguousarray(std["descriptor"])) == e["keys_sha1"]["descr_u8"]
         print(name, "keys", len(std), "xyst exact", exact_xyst, "descr exact", exact_descr)
         assert exact_xyst and exact_descr
+
+
+# Diagnostic switches, read when a context is created.  Each selects another route through the
+# same arithmetic and must give the same bytes as the default route.
+SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
+            {"SIFT_AMD_GRAPH": "0"},      # no hipGraph replay
+            {"SIFT_AMD_DEBUG": "1"},      # generic descriptor instantiation
+            {"SIFT_AMD_DEBUG": "2"},      # descriptor contributions listed per cell instead of per bin
+            {"SIFT_AMD_DEBUG": "3"}]      # per-cell lists with the generic list walk
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+@pytest.mark.parametrize("name", ["white_200x150", "natural_800x640_a", "white_333x257_spo4"])
+def test_diagnostic_switches_give_the_same_records(hip, monkeypatch, name, env):
+    e = INDEX[name]
+    img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
+    p = abi.SiftParameters.default().copy(**e["params"])
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with sift_amd.Context(e["w"], e["h"], 2, p) as ctx:
+        for _ in range(3):                                    # plain launches, graph build, replay
+            ctx.detect_host(np.stack([img, img]))
+            for b in range(2):
+                std, keys = ctx.keypoints(b)
+                orih, descr, _ = ctx.extras(b)
+                assert len(std) == e["n_keys"]
+                xyst = np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1)
+                assert np.array_equal(xyst.view(np.uint32), g["flts"][:, :4].view(np.uint32))
+                assert np.array_equal(std["descriptor"], g["descr"])
+                assert np.array_equal(orih.view(np.uint32), g["orihist"].view(np.uint32))
+        sizes, _ = ctx.stage_counts(0)
+        assert sizes[1:].tolist() == [sum(e["stage_counts_per_octave"][s]) for s in "BCDEF"]

@@ -219,6 +219,17 @@ def test_list_overflow_is_reported_not_silent(hip, monkeypatch):
             with pytest.raises(sift_amd.api.SiftAmdError) as e:
                 ctx.counts()
             assert "overflow" in str(e.value)
+            # every later reader of this run's results gets the same error, not a truncated list
+            for read in (ctx.counts, ctx.keypoints, ctx.gather, ctx.candidates, ctx.extras, ctx.stage_counts):
+                with pytest.raises(sift_amd.api.SiftAmdError) as e:
+                    read()
+                assert "overflow" in str(e.value), read
+            buf = np.zeros(16, abi.KEYPOINT_STD_DTYPE)
+            assert ctx.L.sift_amd_fetch_keypoints(ctx.ptr, 0, buf.ctypes.data, None, 16) < 0
+            # the next run of the same context starts clean (it overflows again, for the same reason)
+            ctx.detect_host(img)
+            with pytest.raises(sift_amd.api.SiftAmdError):
+                ctx.counts()
     monkeypatch.delenv("SIFT_AMD_CAP")
     with sift_amd.Context(w, h) as ctx:      # and the library is fine afterwards
         ctx.detect_host(img)

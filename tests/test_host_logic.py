@@ -85,3 +85,45 @@ def test_sharded_gather_is_independent_of_world_size(tmp_path, world):
         want.append(arr)
     assert counts.tolist() == [len(a) for a in want]
     assert np.array_equal(got, np.concatenate(want).view(np.uint8))
+
+
+def test_launch_plan_covers_a_shard_without_straddling_the_pool():
+    for begin, end, batch in ((0, 0, 8), (0, 4096, 128), (1365, 2731, 128), (5, 6, 4), (3, 29, 8), (512, 1024, 128)):
+        plan = shard.launch_plan(begin, end, batch)
+        covered = [g for g0, n in plan for g in range(g0, g0 + n)]
+        assert covered == list(range(begin, end))
+        assert all(1 <= n <= batch and g0 % batch + n <= batch for g0, n in plan)
+    assert shard.launch_plan(0, 4096, 128) == [(k * 128, 128) for k in range(32)]
+
+
+def _plan_worker(rank, world, port, total, batch, out_path):
+    """The strong-scaling loop of bench.py with a stand-in for the detector: image g of the batch
+    is pool image g % batch, and its result depends on the pool image only."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pool_result = (np.arange(batch) * 7919 + 13) % 1000
+    lo, hi = shard.shard_bounds(total, world, rank)
+    counts = np.zeros(hi - lo, np.int64)
+    for g0, n in shard.launch_plan(lo, hi, batch):
+        counts[g0 - lo:g0 - lo + n] = pool_result[g0 % batch:g0 % batch + n]
+    got = shard.gather_counts(lo, counts, dist)
+    if rank == 0:
+        np.save(out_path, got)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_strong_scaling_counts_are_independent_of_world_size(tmp_path, world):
+    import torch.multiprocessing as mp
+    total, batch = 101, 8
+    out = str(tmp_path / "counts.npy")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_plan_worker, args=(world, port, total, batch, out), nprocs=world, join=True)
+    want = ((np.arange(total) % batch) * 7919 + 13) % 1000
+    assert np.array_equal(np.load(out), want)
+    assert np.array_equal(shard.gather_counts(0, want), want)       # single process: passthrough

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--sigma-min", type=float, default=0.8)
     ap.add_argument("--sigma-in", type=float, default=0.5)
     ap.add_argument("--roofline", action="store_true", help="print the per-kernel HBM roofline table")
+    ap.add_argument("--scalespace-only", action="store_true", help="run only the scale-space launches")
     a = ap.parse_args()
     imgs = np.stack([synth.make(a.kind, a.w, a.h, 12345 + b) for b in range(min(a.batch, 4))])
     imgs = np.concatenate([imgs] * ((a.batch + len(imgs) - 1) // len(imgs)))[:a.batch]
@@ -43,8 +44,12 @@ def main():
     for c in range(api.K_COUNT):
         ctx.profile_read(c, -1, reset=True)
     for _ in range(a.iters):
-        ctx.detect_device(d.data_ptr(), a.batch, st)
-        ctx.counts()
+        if a.scalespace_only:
+            ctx.scalespace_device(d.data_ptr(), a.batch, st)
+            torch.cuda.synchronize()
+        else:
+            ctx.detect_device(d.data_ptr(), a.batch, st)
+            ctx.counts()
     tot = 0.0
     for c in range(api.K_COUNT):
         ms, n = ctx.profile_read(c, -1)
@@ -58,6 +63,14 @@ def main():
         tot += ms / a.iters
         print(f"{api.KERNEL_CLASSES[c]:12s} {ms / a.iters:8.3f} ms/iter  ({n // a.iters} launches)  " + " ".join(per_oct))
     print(f"sum {tot:.3f} ms/iter for {a.batch} images -> {tot / a.batch * 1e3:.1f} us/image")
+    g = ctx.geometry
+    for o in range(min(ctx.n_oct, 3)):
+        row = []
+        for s in range(ctx.n_sca):
+            ms, n = ctx.profile_read_blur(o, s)
+            if n:
+                row.append(f"s{s}(R{g.blur_radius[o][s]}):{ms / n:.3f}")
+        print(f"blur launches octave {o}: " + " ".join(row))
     if a.roofline:
         roofline_table(ctx, a)
 
