@@ -176,6 +176,8 @@ struct sift_amd_ctx {
     int* d_stage = nullptr;
     int* d_counters = nullptr;
     int* d_flist = nullptr;
+    unsigned long long* d_skey = nullptr;   // survivors of all filters, unordered: seed key, candidate index
+    int* d_sidx = nullptr;
     SaKey* d_given = nullptr;       // keypoints supplied by the caller (description-only entry points)
     int* d_ori_n = nullptr;
     float *d_ori_theta = nullptr, *d_ori_hist = nullptr;
@@ -386,6 +388,8 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
         for (int o = 0; o < L->n_oct; o++) c->d_cells[o] = cells + off[o];
     }
     if (dev_alloc(c, &c->d_flist, (size_t)(B * c->fcap))) return fail();
+    if (dev_alloc(c, &c->d_skey, (size_t)(B * c->fcap))) return fail();
+    if (dev_alloc(c, &c->d_sidx, (size_t)(B * c->fcap))) return fail();
     if (dev_alloc(c, &c->d_given, (size_t)(B * c->fcap))) return fail();
     if (dev_alloc(c, &c->d_ori_n, (size_t)(B * c->fcap))) return fail();
     if (dev_alloc(c, &c->d_ori_theta, (size_t)(B * c->fcap * SA_MAX_PEAKS))) return fail();
@@ -619,9 +623,10 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
         }
     }
     { ProfScope ps(c, st, SIFT_AMD_K_REFINE, 0);
-      sa::launch_refine(st, c->pyr, c->sc, c->d_ckey, c->d_cval, c->d_counters, c->cap, c->d_ref, c->d_stage, n); }
+      sa::launch_refine(st, c->pyr, c->sc, c->d_ckey, c->d_cval, c->d_counters, c->cap, c->d_ref, c->d_stage,
+                        c->d_skey, c->d_sidx, c->fcap, n); }
     { ProfScope ps(c, st, SIFT_AMD_K_RANK, 0);
-      sa::launch_rank(st, c->d_ckey, c->d_stage, c->d_counters, c->cap, c->d_flist, c->fcap, n); }
+      sa::launch_rank(st, c->d_skey, c->d_sidx, c->d_counters, c->d_flist, c->fcap, n); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("detection launch failed: %s", hipGetErrorString(e)); return -1; }
     return 0;
@@ -910,22 +915,28 @@ __global__ void __launch_bounds__(256) k_copy_ceiling(const sa_v4f* __restrict__
     for (; i < b1; i += 256) out[i] = in[i];
 }
 
-// The rate at which this GPU executes plain (non-fused) float32 multiplies and adds when
-// nothing else limits them: every thread runs 16 independent mul+add chains from registers.
-// The blur's arithmetic is of this kind (each product and each sum rounded separately, as the
-// reference prescribes), so this is the arithmetic ceiling its large radii run against.
-__global__ void __launch_bounds__(256) k_valu_ceiling(float* out, int iters, float a, float b)
+// The rate at which this GPU executes non-fused float32 multiplies and adds when nothing else
+// limits them: every thread runs 8 independent chains of packed multiply + packed add
+// (v_pk_mul_f32 / v_pk_add_f32, operands in vector registers), the form the blur's arithmetic
+// takes (each product and each sum rounded separately, as the reference prescribes) and the
+// fastest one on gfx950: a packed instruction does two lane-operations in ~1.7x the issue time
+// of a plain one, and a plain one with a scalar-register operand takes as long as a packed one.
+typedef float sa_v2f __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_valu_ceiling(float* out, int iters)
 {
-    float acc[16];
+    sa_v2f acc[8];
+    // multiplier and addend live in vector registers (values depend on the lane)
+    const sa_v2f a = {0.999f + 1e-6f * (threadIdx.x & 3), 0.998f + 1e-6f * (threadIdx.x & 1)};
+    const sa_v2f b = {0.001f + 1e-6f * (threadIdx.x & 7), 0.002f};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = (float)(threadIdx.x + k);
+    for (int k = 0; k < 8; ++k) acc[k] = sa_v2f{(float)(threadIdx.x + k), (float)k};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) acc[k] = __fadd_rn(__fmul_rn(acc[k], a), b);
+        for (int k = 0; k < 8; ++k) acc[k] = acc[k] * a + b;
     }
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s += acc[k];
+    for (int k = 0; k < 8; ++k) s += acc[k].x + acc[k].y;
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -941,11 +952,11 @@ extern "C" int sift_amd_valu_ceiling(int device, int reps, double* lane_gops)
     do {
         if (hipMalloc((void**)&d, 256) != hipSuccess) break;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-        hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters, 0.999f, 0.001f);
+        hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters);
         if (hipDeviceSynchronize() != hipSuccess) break;
         (void)hipEventRecord(e0, nullptr);
         for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters, 0.999f, 0.001f);
+            hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters);
         (void)hipEventRecord(e1, nullptr);
         if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
         *lane_gops = (double)blocks * 256 * iters * 32.0 * reps / (ms * 1e-3) / 1e9;

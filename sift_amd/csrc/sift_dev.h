@@ -19,6 +19,7 @@ enum {
     SA_CNT_KEYS = 3,      // oriented keypoints (final list length)
     SA_CNT_STAGE = 4,     // [4..9]   stage sizes A..F (A = all discrete extrema)
     SA_CNT_EXT_OCT = 10,  // [10..25] discrete extrema per octave
+    SA_CNT_SURV = 26,     // survivors of all filters appended (unordered) by the refinement kernel
     SA_CNT_STRIDE = 32
 };
 

@@ -259,6 +259,17 @@ __device__ __forceinline__ v2f win_pair(const v2f* p, int a)
 // Taps duplicated into pairs: packed multiplies take them straight from SGPR pairs.
 struct SaTapPairs { v2f g[SA_MAX_RADIUS_FAST + 1]; };
 
+#ifdef SA_BLUR_CLOCK
+// Diagnostic build only: shader-clock ticks and 100 MHz real-time ticks spent inside the blur
+// blocks, per radius, to read the clock the GPU holds while the kernel runs.
+__device__ unsigned long long sa_blur_clock[2 * (SA_MAX_RADIUS_FAST + 1)];
+extern "C" void sift_amd_debug_blur_clock(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_blur_clock), sizeof(sa_blur_clock));
+    if (reset) { unsigned long long z[2 * (SA_MAX_RADIUS_FAST + 1)] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(sa_blur_clock), z, sizeof(z)); }
+}
+#endif
+
 // OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
 // version at step `delta`, evaluated on the fly (w x h is the oversampled size).
 
@@ -273,6 +284,9 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     // the row pass free of bank conflicts also where a wave straddles two rows.
     constexpr int G = 8, RP = 16, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
     constexpr int ITEMS = G * NG;
+#ifdef SA_BLUR_CLOCK
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     __shared__ __attribute__((aligned(16))) float l_tmp[NBUF][G][PITCH];
     __shared__ __attribute__((aligned(16))) float l_prev[NBUF][G][PITCH];
     const int tid = threadIdx.x;
@@ -508,6 +522,12 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
     }
+#ifdef SA_BLUR_CLOCK
+    if (tid == 0 && !OVS) {
+        atomicAdd(&sa_blur_clock[2 * R], __builtin_amdgcn_s_memtime() - clk_t0);
+        atomicAdd(&sa_blur_clock[2 * R + 1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+    }
+#endif
 }
 
 // Any radius (taps in global memory); one thread per output sample.  Only used for
@@ -817,7 +837,8 @@ __device__ __forceinline__ void taylor3d(const float* __restrict__ st, int w, in
 __global__ void __launch_bounds__(256)
 k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
          const float* __restrict__ cval, int* __restrict__ counters, int cap,
-         SaKey* __restrict__ ref, int* __restrict__ stage)
+         SaKey* __restrict__ ref, int* __restrict__ stage,
+         unsigned long long* __restrict__ skey, int* __restrict__ sidx, int fcap)
 {
     const long long b = blockIdx.y;
     int* cnt = counters + b * SA_CNT_STRIDE;
@@ -884,7 +905,14 @@ k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
                         const float ls = k.sigma;  // lambda = 1
                         const bool in = (__fsub_rn(k.x, ls) > 0.f) && (__fadd_rn(k.x, ls) < (float)P.im_h)
                                      && (__fsub_rn(k.y, ls) > 0.f) && (__fadd_rn(k.y, ls) < (float)P.im_w);
-                        if (in) { stg = SA_ST_F; ++nF; }
+                        if (in) {
+                            stg = SA_ST_F; ++nF;
+                            // survivors are few: each appends its seed key and candidate index to a
+                            // compact list, from which k_rank derives the reference's list order
+                            const int slot = atomicAdd(&cnt[SA_CNT_SURV], 1);
+                            if (slot < fcap) { skey[b * fcap + slot] = key; sidx[b * fcap + slot] = c; }
+                            else cnt[SA_CNT_OVERFLOW] = 1;
+                        }
                     }
                 }
             }
@@ -902,38 +930,33 @@ k_refine(SaPyramid P, SaScalars sc, const unsigned long long* __restrict__ ckey,
 
 // ----------------------------------------------------- canonical ordering --
 // The reference lists are in lexicographic (o,s,i,j) order of the discrete extremum that
-// seeded each keypoint.  Survivors of all filters are few, so each one simply counts how
-// many surviving seeds precede it (keys are unique) and stores itself at that rank.
+// seeded each keypoint.  The survivors of all filters (compacted, in no particular order, by
+// k_refine) are few, so each one simply counts how many survivors have a smaller seed key
+// (keys are unique) and stores its candidate index at that rank.
 __global__ void __launch_bounds__(256)
-k_rank(const unsigned long long* __restrict__ ckey, const int* __restrict__ stage,
-       int* __restrict__ counters, int cap, int* __restrict__ flist, int fcap)
+k_rank(const unsigned long long* __restrict__ skey, const int* __restrict__ sidx,
+       int* __restrict__ counters, int* __restrict__ flist, int fcap)
 {
     __shared__ unsigned long long tile[1024];
     const long long b = blockIdx.y;
     int* cnt = counters + b * SA_CNT_STRIDE;
-    const int n = min(cnt[SA_CNT_CAND], cap);
+    const int n = min(cnt[SA_CNT_SURV], fcap);
     for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
-        const int c = base + threadIdx.x;
-        const bool mine = c < n && stage[b * cap + c] == SA_ST_F;
-        const unsigned long long key = mine ? ckey[b * cap + c] : 0ull;
+        const int q = base + threadIdx.x;
+        const bool mine = q < n;
+        const unsigned long long key = mine ? skey[b * fcap + q] : 0ull;
         int rank = 0;
         for (int t0 = 0; t0 < n; t0 += 1024) {
             __syncthreads();
-            for (int t = threadIdx.x; t < 1024; t += 256) {
-                const int cc = t0 + t;
-                tile[t] = (cc < n && stage[b * cap + cc] == SA_ST_F) ? ckey[b * cap + cc] : ~0ull;
-            }
+            for (int t = threadIdx.x; t < 1024; t += 256) tile[t] = t0 + t < n ? skey[b * fcap + t0 + t] : ~0ull;
             __syncthreads();
             const int lim = min(1024, n - t0);
             if (mine)
                 for (int t = 0; t < lim; ++t) rank += tile[t] < key;
         }
-        if (mine) {
-            if (rank < fcap) flist[b * fcap + rank] = c;
-            else cnt[SA_CNT_OVERFLOW] = 1;
-        }
+        if (mine) flist[b * fcap + rank] = sidx[b * fcap + q];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[SA_CNT_NF] = min(cnt[SA_CNT_STAGE + SA_ST_F], fcap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[SA_CNT_NF] = n;
 }
 
 // --------------------------------------------------- orientation histogram --
@@ -1124,8 +1147,9 @@ k_expand(const SaKey* __restrict__ keys, const int* __restrict__ index, int* __r
 
 // One 64-lane wave owns a keypoint, so no block-wide barriers are needed, and the samples that
 // fall inside the rotated window are first queued (in raster order) so that the expensive
-// double-precision part always runs on full waves.  Lane l owns the BPL consecutive descriptor
-// bins l*BPL .. l*BPL+BPL-1.
+// double-precision part always runs on full waves.  Lane l owns the BPL descriptor bins
+// l, l+64, l+128, ...: a batch of 64 raster-consecutive samples touches only one or two rows of
+// cells, i.e. a contiguous range of bins, and this spreads that range over all lanes.
 // array_l2norm (lib_util.c:156-164) over LDS by one lane: sequential float sum, four values
 // per LDS read.
 __device__ __forceinline__ float seq_l2norm(const float* d, int n)
@@ -1187,15 +1211,15 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     int my_cell[BPL], my_ci[BPL], my_cj[BPL], my_k[BPL], my_kprev[BPL];
 #pragma unroll
     for (int u = 0; u < BPL; ++u) {
-        const int t = lane * BPL + u;
+        const int t = lane + 64 * u;
         my_cell[u] = t < nd ? t / Nb : -1;
         my_ci[u] = t < nd ? my_cell[u] / Nh : 0;
         my_cj[u] = t < nd ? my_cell[u] - my_ci[u] * Nh : 0;
         my_k[u] = t % Nb;
         my_kprev[u] = my_k[u] == 0 ? Nb - 1 : my_k[u] - 1;
     }
-    // all bins of a lane lie in one cell (always true for the default 4x4x8 shape)
-    const bool one_cell = (Nb % BPL) == 0 && !(sc.debug & 1);
+    // all bins of a lane lie in one cell
+    const bool one_cell = BPL == 1 && !(sc.debug & 1);
     // One list per descriptor bin instead of one per cell: a lane then touches only the
     // contributions of its own bins.  Needs a lane per orientation bin for the bookkeeping.
     const bool bin_lists = NB ? true : (Nb <= 64 && !(sc.debug & 2));   // (fixed shapes: launched without debug switches)
@@ -1349,7 +1373,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
 #pragma unroll
                     for (int u = 0; u < BPL; ++u) {
                         start[u] += excl;
-                        if (my_cell[u] >= 0) bstart_s[lane * BPL + u] = start[u];
+                        if (my_cell[u] >= 0) bstart_s[lane + 64 * u] = start[u];
                         // odd lists end with +0.0, which leaves the non-negative accumulator as it is
                         if (cnt[u] & 1) pool[start[u] + cnt[u]] = 0.0;
                     }
@@ -1373,18 +1397,31 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 }
                 __syncthreads();
                 PROF_T(8)
-                // ---- every lane adds the lists of its bins, in order, next value loaded ahead
-                // (two entries per 16-byte read)
-#pragma unroll
-                for (int u = 0; u < BPL; ++u) {
+                // ---- every lane adds the lists of its bins, in order.  A lane's lists lie one after
+                // the other in the pool, so they are walked as one sequence of pairs (two entries per
+                // 16-byte read, the next pair loaded while the current one is added) whose
+                // accumulator changes at the list boundaries: the wave is busy for the longest
+                // per-lane total, not for the sum of the longest lists.
+                {
                     typedef double v2d __attribute__((ext_vector_type(2)));
-                    const v2d* pl = reinterpret_cast<const v2d*>(pool) + (start[u] >> 1);
-                    const int np = (cnt[u] + 1) >> 1;
+                    const v2d* pl = reinterpret_cast<const v2d*>(pool) + (start[0] >> 1);
+                    int bound[BPL];
+                    int total = 0;
+#pragma unroll
+                    for (int u = 0; u < BPL; ++u) { total += (cnt[u] + 1) >> 1; bound[u] = total; }
                     v2d v = pl[0];
-                    for (int e = 0; e < np; ++e) {
+                    for (int e = 0; e < total; ++e) {
                         const v2d nv = pl[e + 1];
-                        acc[u] = (float)((double)acc[u] + v.x);
-                        acc[u] = (float)((double)acc[u] + v.y);
+                        int sel = 0;
+#pragma unroll
+                        for (int u = 0; u + 1 < BPL; ++u) sel += e >= bound[u];
+                        float a = acc[0];
+#pragma unroll
+                        for (int u = 1; u < BPL; ++u) a = sel == u ? acc[u] : a;
+                        a = (float)((double)a + v.x);
+                        a = (float)((double)a + v.y);
+#pragma unroll
+                        for (int u = 0; u < BPL; ++u) acc[u] = sel == u ? a : acc[u];
                         v = nv;
                     }
                 }
@@ -1482,7 +1519,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
         }
 #pragma unroll
         for (int u = 0; u < BPL; ++u)
-            if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
+            if (lane + 64 * u < nd) d_s[lane + 64 * u] = acc[u];
         __syncthreads();
         // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
         if (lane == 0) norm_s = seq_l2norm(d_s, nd);
@@ -1491,14 +1528,14 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
 #pragma unroll
         for (int u = 0; u < BPL; ++u) {
             acc[u] = fminf(acc[u], cap);
-            if (lane * BPL + u < nd) d_s[lane * BPL + u] = acc[u];
+            if (lane + 64 * u < nd) d_s[lane + 64 * u] = acc[u];
         }
         __syncthreads();
         if (lane == 0) norm_s = seq_l2norm(d_s, nd);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < BPL; ++u) {
-            const int t = lane * BPL + u;
+            const int t = lane + 64 * u;
             if (t < nd) {
                 float v = (float)(int)((double)acc[u] * 512.0 / (double)norm_s);
                 v = v < 255.f ? v : 255.f;
@@ -1704,15 +1741,16 @@ int launch_extrema(hipStream_t st, const float* gss, long long s_gss, int w, int
 }
 
 void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,
-                   const float* cval, int* counters, int cap, SaKey* ref, int* stage, int batch)
+                   const float* cval, int* counters, int cap, SaKey* ref, int* stage,
+                   unsigned long long* skey, int* sidx, int fcap, int batch)
 {
-    HIPK(k_refine, dim3(64, batch), dim3(256), 0, st, P, sc, ckey, cval, counters, cap, ref, stage);
+    HIPK(k_refine, dim3(64, batch), dim3(256), 0, st, P, sc, ckey, cval, counters, cap, ref, stage, skey, sidx, fcap);
 }
 
-void launch_rank(hipStream_t st, const unsigned long long* ckey, const int* stage, int* counters, int cap,
+void launch_rank(hipStream_t st, const unsigned long long* skey, const int* sidx, int* counters,
                  int* flist, int fcap, int batch)
 {
-    HIPK(k_rank, dim3(32, batch), dim3(256), 0, st, ckey, stage, counters, cap, flist, fcap);
+    HIPK(k_rank, dim3(8, batch), dim3(256), 0, st, skey, sidx, counters, flist, fcap);
 }
 
 void launch_orientation(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,

@@ -41,8 +41,9 @@ int launch_extrema(hipStream_t st, const float* gss, long long s_gss, int w, int
                    float thr_pre, int emit_all, unsigned long long* ckey, float* cval,
                    int* counters, int cap, int batch, const int* flags);
 void launch_refine(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const unsigned long long* ckey,
-                   const float* cval, int* counters, int cap, SaKey* ref, int* stage, int batch);
-void launch_rank(hipStream_t st, const unsigned long long* ckey, const int* stage, int* counters, int cap,
+                   const float* cval, int* counters, int cap, SaKey* ref, int* stage,
+                   unsigned long long* skey, int* sidx, int fcap, int batch);
+void launch_rank(hipStream_t st, const unsigned long long* skey, const int* sidx, int* counters,
                  int* flist, int fcap, int batch);
 void launch_orientation(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
                         const int* index, const int* counters, int cnt_slot, int kcap, int icap, int mode,

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   timeout -s KILL 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- \
-      python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --pipeline 1 > $OUT/$name.log 2>&1
+      python3 $ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu --no-extras --pipeline 1 > $OUT/$name.log 2>&1
   echo "pass $name done"
 }
 run fetch FETCH_SIZE

@@ -13,9 +13,9 @@ DOM_THREADS=512
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
-    python3 $ROOT/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+    python3 $ROOT/bench.py --no-cpu --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 cd $ROOT
-python3 tools/prof_summary.py $OUT/stats 33 > $OUT/kernel_stats.md
+python3 tools/prof_summary.py $OUT/stats > $OUT/kernel_stats.md
 python3 tools/trace_by_grid.py $OUT/stats "" 40 > $OUT/by_grid.txt
 python3 tools/dominant_from_trace.py $OUT/stats $DOM_BLOCKS 50 > $OUT/dominant_kernel_rocprof.txt
 bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
@@ -24,16 +24,13 @@ python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)) $BATCH $OUT
 [ -s $OUT/traffic.json ] && cp $OUT/traffic.json $ROOT/profiles/traffic.json   # the bench line quotes it
 bash tools/pmc_one.sh $TAG/grbm GRBM_GUI_ACTIVE > $OUT/grbm.log 2>&1
 python3 tools/clock_from_pmc.py $OUT/grbm > $OUT/clock_per_kernel.md
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-# secondary measurements: keypoint-rich input, host-resident input, one batch at a time
-timeout -k 10 300 python3 bench.py --no-cpu --kind white > $OUT/bench_white.json 2>> $OUT/bench.err
-timeout -k 10 300 python3 bench.py --no-cpu --host-input > $OUT/bench_host_input.json 2>> $OUT/bench.err
-timeout -k 10 300 python3 bench.py --no-cpu --host-input-u8 > $OUT/bench_host_input_u8.json 2>> $OUT/bench.err
-timeout -k 10 300 python3 bench.py --no-cpu --pipeline 1 > $OUT/bench_pipeline1.json 2>> $OUT/bench.err
-timeout -k 10 200 python3 tools/kernel_bench.py --batch 64 --roofline > $OUT/per_kernel_roofline_b64.md 2>&1
+timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 300 python3 bench.py --no-cpu --no-extras --pipeline 1 > $OUT/bench_pipeline1.json 2>> $OUT/bench.err
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 128 --roofline > $OUT/per_kernel_roofline_b128.md 2>&1
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 128 --kind white > $OUT/per_kernel_white_b128.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 > $OUT/per_kernel_single_1080p.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 --w 3840 --h 2160 > $OUT/per_kernel_single_4k.md 2>&1
 # what the hardware gives: copy ceiling of HBM, issue rate of packed against plain f32 instructions
 hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/copy_bw tools/membench/copy_bw.hip && timeout -k 10 120 /tmp/copy_bw > $OUT/micro_copy_bw.txt
-hipcc --offload-arch=gfx950 -O2 -Wno-unused-value -o /tmp/valu_rate tools/membench/valu_rate.hip && timeout -k 10 120 /tmp/valu_rate > $OUT/micro_valu_rate.txt
+hipcc --offload-arch=gfx950 -O2 -w -o /tmp/valu_sgpr tools/membench/valu_sgpr.hip && timeout -k 10 120 /tmp/valu_sgpr > $OUT/micro_valu_rate.txt
 echo done
