@@ -14,7 +14,8 @@ import numpy as np
 from . import abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsift_amd.so")
+# SIFT_AMD_LIB: another build of the same library (A/B runs of the tools); never a fallback
+LIB_PATH = os.environ.get("SIFT_AMD_LIB") or os.path.join(HERE, "libsift_amd.so")
 
 MAX_OCT, MAX_SCA = 16, 12
 K_OVERSAMPLE, K_SUBSAMPLE, K_BLUR_V, K_BLUR_H, K_EXTREMA, K_REFINE, K_RANK, K_ORIENTATION, \

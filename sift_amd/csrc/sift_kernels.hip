@@ -959,16 +959,32 @@ k_rank(const unsigned long long* __restrict__ skey, const int* __restrict__ sidx
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[SA_CNT_NF] = n;
 }
 
-// --------------------------------------------------- orientation histogram --
-__device__ __forceinline__ float modulus_f(float x, float y)   // lib_util.c:187-198
+// RN(a / b) for a denominator b whose correctly rounded reciprocal y is at hand three instructions
+// instead of a full division.  With y = RN(1/b), q = RN(a*y), r = a - b*q (exact in an FMA),
+// RN(q + r*y) is RN(a/b) (Markstein's theorem; the operands here are far from the overflow and
+// underflow ranges).
+__device__ __forceinline__ float div_by_uniform(float a, float b, float y)
 {
+    const float q = __fmul_rn(a, y);
+    return __fmaf_rn(__fmaf_rn(-b, q, a), y, q);
+}
+__device__ __forceinline__ double div_by_uniform(double a, double b, double y)
+{
+    const double q = __dmul_rn(a, y);
+    return __fma_rn(__fma_rn(-b, q, a), y, q);
+}
+
+// --------------------------------------------------- orientation histogram --
+__device__ __forceinline__ float modulus_2pi(float x)   // lib_util.c:187-198 with y = 2*pi
+{
+    constexpr float y = (float)(2 * SA_PI), yr = 1.0f / y;
     float z = x;
     int n;
     if (z < 0) {
-        n = (int)__fdiv_rn(-z, y) + 1;
+        n = (int)div_by_uniform(-z, y, yr) + 1;
         z = __fadd_rn(z, __fmul_rn((float)n, y));
     }
-    n = (int)__fdiv_rn(z, y);
+    n = (int)div_by_uniform(z, y, yr);
     z = __fsub_rn(z, __fmul_rn((float)n, y));
     return z;
 }
@@ -1018,6 +1034,7 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
         const int nw = j1 - j0 + 1, nh = i1 - i0 + 1;
         const int npix = (nw > 0 && nh > 0) ? nw * nh : 0;
         const float denom = __fmul_rn(__fmul_rn(2.f, sc.lambda_ori), sc.lambda_ori);
+        const float sk_rcp = __fdiv_rn(1.f, sk), denom_rcp = __fdiv_rn(1.f, denom);
         float hb = 0.f;
         // (row, column) of raster position p0 + lane, advanced by 64 positions per chunk
         int fi = 0, fj = 0;
@@ -1028,15 +1045,18 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
             float M = 0.f;
             if (p < npix) {
                 const int si = i0 + fi, sj = j0 + fj;
-                const float sX = __fdiv_rn(__fsub_rn((float)si, xk), sk);
-                const float sY = __fdiv_rn(__fsub_rn((float)sj, yk), sk);
+                const float sX = div_by_uniform(__fsub_rn((float)si, xk), sk, sk_rcp);
+                const float sY = div_by_uniform(__fsub_rn((float)sj, yk), sk, sk_rcp);
                 const float dx = grad_i(im, w, h, si, sj);
                 const float dy = grad_j(im, w, h, si, sj);
-                float ori = modulus_f((float)atan2((double)dy, (double)dx), (float)(2 * SA_PI));
+                float ori = modulus_2pi((float)atan2((double)dy, (double)dx));
                 const float r2 = __fadd_rn(__fmul_rn(sX, sX), __fmul_rn(sY, sY));
-                M = (float)(hypot((double)dx, (double)dy) * exp((double)__fdiv_rn(-r2, denom)));
+                // (dx, dy are floats: their squares are exact in double, so the root of the sum is
+                // within an ulp of hypot() without its scaling steps)
+                M = (float)(sqrt((double)dx * (double)dx + (double)dy * (double)dy) *
+                            exp((double)div_by_uniform(-r2, denom, denom_rcp)));
                 if (ori < 0) ori = (float)((double)ori + 2 * SA_PI);
-                bin = (int)((double)ori / (2 * SA_PI) * nbins + 0.5);
+                bin = (int)(div_by_uniform((double)ori, 2 * SA_PI, 1.0 / (2 * SA_PI)) * nbins + 0.5);
                 bin = (unsigned)bin < 2u * (unsigned)nbins ? (bin >= nbins ? bin - nbins : bin) : bin % nbins;
             }
             fj += 64;
@@ -1168,6 +1188,40 @@ __device__ __forceinline__ float seq_l2norm(const float* d, int n)
     return (float)sqrt((double)l2);
 }
 
+// Ballots into lanes: lane L of (lo, hi) receives mask m[L].  A ballot lives in an SGPR pair and
+// v_writelane_b32 drops each half into one lane of a VGPR.  Two hazards that the compiler does not
+// handle inside asm statements (measured with tools/membench/writelane_test.hip): v_writelane must
+// not read an SGPR in the cycle after the v_cmp that wrote it, hence all compares first, then wait
+// states, then the writes; and a DPP read of the VGPR needs two wait states after its last write.
+#define SA_WL(lo, hi, m, L)                                                                           \
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((int)(unsigned)(m)), "n"(L));          \
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((int)(unsigned)((m) >> 32)), "n"(L));
+__device__ __forceinline__ void masks_to_lanes8(int key, int& lo, int& hi)
+{
+    unsigned long long m[8];
+#pragma unroll
+    for (int L = 0; L < 8; ++L) m[L] = __ballot(key == L);
+    asm volatile("s_nop 4" :: "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(m[4]), "s"(m[5]), "s"(m[6]), "s"(m[7]));
+    SA_WL(lo, hi, m[0], 0) SA_WL(lo, hi, m[1], 1) SA_WL(lo, hi, m[2], 2) SA_WL(lo, hi, m[3], 3)
+    SA_WL(lo, hi, m[4], 4) SA_WL(lo, hi, m[5], 5) SA_WL(lo, hi, m[6], 6) SA_WL(lo, hi, m[7], 7)
+    asm volatile("s_nop 1" : "+v"(lo), "+v"(hi));
+}
+// the same for keys -1..3 of two variables at once (lane L: key == L - 1)
+__device__ __forceinline__ void masks_to_lanes5x2(int ka, int kb, int& alo, int& ahi, int& blo, int& bhi)
+{
+    unsigned long long ma[5], mb[5];
+#pragma unroll
+    for (int L = 0; L < 5; ++L) { ma[L] = __ballot(ka == L - 1); mb[L] = __ballot(kb == L - 1); }
+    asm volatile("s_nop 4" :: "s"(ma[0]), "s"(ma[1]), "s"(ma[2]), "s"(ma[3]), "s"(ma[4]),
+                 "s"(mb[0]), "s"(mb[1]), "s"(mb[2]), "s"(mb[3]), "s"(mb[4]));
+    SA_WL(alo, ahi, ma[0], 0) SA_WL(alo, ahi, ma[1], 1) SA_WL(alo, ahi, ma[2], 2) SA_WL(alo, ahi, ma[3], 3)
+    SA_WL(alo, ahi, ma[4], 4)
+    SA_WL(blo, bhi, mb[0], 0) SA_WL(blo, bhi, mb[1], 1) SA_WL(blo, bhi, mb[2], 2) SA_WL(blo, bhi, mb[3], 3)
+    SA_WL(blo, bhi, mb[4], 4)
+    asm volatile("s_nop 1" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi));
+}
+#undef SA_WL
+
 #ifdef SA_DESCR_PROF
 __device__ unsigned long long sa_prof[16];
 extern "C" void sift_amd_debug_prof(unsigned long long* out, int reset)
@@ -1208,10 +1262,15 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
     const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], kcap);
     const int Nh = NH ? NH : sc.n_hist, Nb = NB ? NB : sc.n_ori, nd = Nh * Nh * Nb, ncell = Nh * Nh;
     const unsigned long long lt = lanemask_lt();
-    int my_cell[BPL], my_ci[BPL], my_cj[BPL], my_k[BPL], my_kprev[BPL];
+    int my_t[BPL], my_cell[BPL], my_ci[BPL], my_cj[BPL], my_k[BPL], my_kprev[BPL];
 #pragma unroll
     for (int u = 0; u < BPL; ++u) {
-        const int t = lane + 64 * u;
+        // Default shape: a lane's second bin lies two cell rows further down and four orientation
+        // bins away.  Orientations are measured from the keypoint's dominant one, so the bins around
+        // zero collect the longest lists in every cell; pairing bin k with bin k+4 evens out what the
+        // lanes have to add.
+        const int t = (NB == 8 && BPL == 2 && u == 1) ? 64 + (lane & ~7) + ((lane + 4) & 7) : lane + 64 * u;
+        my_t[u] = t;
         my_cell[u] = t < nd ? t / Nb : -1;
         my_ci[u] = t < nd ? my_cell[u] / Nh : 0;
         my_cj[u] = t < nd ? my_cell[u] - my_ci[u] * Nh : 0;
@@ -1249,6 +1308,11 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
         const double tt = (double)__fmul_rn(sc.lambda_descr, sk);
         const double two_t2 = 2 * tt * tt;
         const float cell = __fdiv_rn(__fmul_rn(__fmul_rn(2.f, sc.lambda_descr), sk), (float)Nh);
+        // Correctly rounded quotients by a denominator that is the same for the whole keypoint:
+        // with y = RN(1/b), q = RN(a*y), r = a - b*q (exact in an FMA), RN(q + r*y) is RN(a/b)
+        // (Markstein's theorem; operands here are far from the overflow and underflow ranges).
+        const float cell_rcp = __fdiv_rn(1.f, cell);
+        const double two_t2_rcp = 1.0 / two_t2;
         const double half = ((double)Nh - 1.0) / 2.0;
         float acc[BPL];
 #pragma unroll
@@ -1282,7 +1346,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
             const int nproc = min(qn, 64);
             const bool act = lane < nproc;
             // ---- geometry of my sample, cell ranks
-            int si = 0, sj = 0, a0 = 0, b0 = 0;
+            int si = 0, sj = 0, a0 = -2, b0 = -2;
             float X = 0.f, Y = 0.f, al = 0.f, be = 0.f;
             if (act) {
                 const int p = q_pix[(qhead + lane) & 127];
@@ -1290,24 +1354,26 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 const float X0 = __fsub_rn((float)si, xk), Y0 = __fsub_rn((float)sj, yk);
                 X = __fsub_rn(__fmul_rn(ct, X0), __fmul_rn(st, Y0));
                 Y = __fadd_rn(__fmul_rn(st, X0), __fmul_rn(ct, Y0));
-                al = (float)((double)__fdiv_rn(X, cell) + half);
-                be = (float)((double)__fdiv_rn(Y, cell) + half);
+                al = (float)((double)div_by_uniform(X, cell, cell_rcp) + half);
+                be = (float)((double)div_by_uniform(Y, cell, cell_rcp) + half);
                 a0 = (int)floor((double)al);
                 b0 = (int)floor((double)be);
             }
             PROF_T(2)
             if (bin_lists) {
                 // ---- my sample's orientation bin pair, weights and magnitude
-                int k0 = 0, k1 = 0;
+                int k0 = -1, k1 = 0;
                 double wl = 0., wr = 0., M = 0.;
                 if (act) {
                     const double dx = (double)grad_i(im, w, h, si, sj);
                     const double dy = (double)grad_j(im, w, h, si, sj);
                     float ori = (float)(atan2(dy, dx) - (double)theta);
-                    ori = modulus_f(ori, (float)(2 * SA_PI));
+                    ori = modulus_2pi(ori);
                     const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
-                    M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
-                    const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
+                    // dx, dy are floats: their squares are exact in double, so the root of the sum
+                    // is within an ulp of hypot() without its scaling steps
+                    M = sqrt(dx * dx + dy * dy) * exp(div_by_uniform((double)(-r2), two_t2, two_t2_rcp));
+                    const float ga = (float)(div_by_uniform((double)ori, 2 * SA_PI, 1.0 / (2 * SA_PI)) * Nb);
                     const double gf = floor((double)ga);
                     k0 = wrap_bin((int)ga, Nb);
                     k1 = k0 + 1 == Nb ? 0 : k0 + 1;
@@ -1317,10 +1383,20 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 PROF_T(3)
                 // ---- kk_s[k]: lanes whose sample adds to orientation bin k (its own bin k0 == k,
                 // or k0 == k-1 through the second weight); lane k collects the mask of k0 == k
-                unsigned long long myK = 0;
-                for (int k = 0; k < Nb; ++k) {
-                    const unsigned long long m = __ballot(act && k0 == k);
-                    if (lane == k) myK = m;
+                unsigned long long myK;
+                {
+                    // (inactive lanes hold k0 = -1; a ballot lives in an SGPR pair and v_writelane
+                    // drops it into lane k)
+                    int lo = 0, hi = 0;
+                    if (NB == 8) {
+                        masks_to_lanes8(k0, lo, hi);
+                    } else {
+                        for (int k = 0; k < Nb; ++k) {
+                            const unsigned long long m = __ballot(k0 == k);
+                            if (lane == k) { lo = (int)(unsigned)m; hi = (int)(unsigned)(m >> 32); }
+                        }
+                    }
+                    myK = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
                 }
                 {
                     // mask of the bin before mine (bin Nb-1 for bin 0)
@@ -1336,11 +1412,21 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                 // (samples with a0 in {ci-1, ci}) & (samples with b0 in {cj-1, cj}).  Lane p collects
                 // the mask of a0 == p-1 (p = 0..Nh), pa_s[p] is the pair mask of cell row p-1.
                 {
-                    unsigned long long tA = 0, tB = 0;
-                    for (int a = -1; a < Nh; ++a) {
-                        const unsigned long long ma_ = __ballot(act && a0 == a), mb_ = __ballot(act && b0 == a);
-                        if (lane == a + 1) { tA = ma_; tB = mb_; }
+                    int alo = 0, ahi = 0, blo = 0, bhi = 0;
+                    if (NH == 4) {
+                        // (inactive lanes hold a0 = b0 = -2)
+                        masks_to_lanes5x2(a0, b0, alo, ahi, blo, bhi);
+                    } else {
+                        for (int a = -1; a < Nh; ++a) {
+                            const unsigned long long ma_ = __ballot(a0 == a), mb_ = __ballot(b0 == a);
+                            if (lane == a + 1) {
+                                alo = (int)(unsigned)ma_; ahi = (int)(unsigned)(ma_ >> 32);
+                                blo = (int)(unsigned)mb_; bhi = (int)(unsigned)(mb_ >> 32);
+                            }
+                        }
                     }
+                    const unsigned long long tA = ((unsigned long long)(unsigned)ahi << 32) | (unsigned)alo;
+                    const unsigned long long tB = ((unsigned long long)(unsigned)bhi << 32) | (unsigned)blo;
                     const unsigned long long pA = lane_prev_u64(tA), pB = lane_prev_u64(tB);
                     if (lane <= Nh + 1) { pa_s[lane] = tA | pA; pb_s[lane] = tB | pB; }
                 }
@@ -1373,7 +1459,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
 #pragma unroll
                     for (int u = 0; u < BPL; ++u) {
                         start[u] += excl;
-                        if (my_cell[u] >= 0) bstart_s[lane + 64 * u] = start[u];
+                        if (my_cell[u] >= 0) bstart_s[my_t[u]] = start[u];
                         // odd lists end with +0.0, which leaves the non-negative accumulator as it is
                         if (cnt[u] & 1) pool[start[u] + cnt[u]] = 0.0;
                     }
@@ -1409,6 +1495,16 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     int total = 0;
 #pragma unroll
                     for (int u = 0; u < BPL; ++u) { total += (cnt[u] + 1) >> 1; bound[u] = total; }
+#ifdef SA_DESCR_PROF
+                    {   // walk statistics: batches, longest and summed per-lane walks, samples
+                        int mx = total, sm = total;
+                        for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); sm += __shfl_xor(sm, d); }
+                        if (lane == 0) {
+                            atomicAdd(&sa_prof[12], 1ull); atomicAdd(&sa_prof[13], (unsigned long long)mx);
+                            atomicAdd(&sa_prof[14], (unsigned long long)sm); atomicAdd(&sa_prof[15], (unsigned long long)nproc);
+                        }
+                    }
+#endif
                     v2d v = pl[0];
                     for (int e = 0; e < total; ++e) {
                         const v2d nv = pl[e + 1];
@@ -1447,7 +1543,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
                     const double dx = (double)grad_i(im, w, h, si, sj);
                     const double dy = (double)grad_j(im, w, h, si, sj);
                     float ori = (float)(atan2(dy, dx) - (double)theta);
-                    ori = modulus_f(ori, (float)(2 * SA_PI));
+                    ori = modulus_2pi(ori);
                     const float r2 = __fadd_rn(__fmul_rn(X, X), __fmul_rn(Y, Y));
                     const double M = hypot(dx, dy) * exp((double)(-r2) / two_t2);
                     const float ga = (float)((double)ori / (2 * SA_PI) * Nb);
@@ -1519,7 +1615,7 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
         }
 #pragma unroll
         for (int u = 0; u < BPL; ++u)
-            if (lane + 64 * u < nd) d_s[lane + 64 * u] = acc[u];
+            if (my_t[u] < nd) d_s[my_t[u]] = acc[u];
         __syncthreads();
         // clip at 0.2*norm, renormalise; norms are sequential float sums as in array_l2norm
         if (lane == 0) norm_s = seq_l2norm(d_s, nd);
@@ -1528,14 +1624,14 @@ descriptor_wave_body(const SaPyramid& P, const SaScalars& sc, const SaKey* __res
 #pragma unroll
         for (int u = 0; u < BPL; ++u) {
             acc[u] = fminf(acc[u], cap);
-            if (lane + 64 * u < nd) d_s[lane + 64 * u] = acc[u];
+            if (my_t[u] < nd) d_s[my_t[u]] = acc[u];
         }
         __syncthreads();
         if (lane == 0) norm_s = seq_l2norm(d_s, nd);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < BPL; ++u) {
-            const int t = lane + 64 * u;
+            const int t = my_t[u];
             if (t < nd) {
                 float v = (float)(int)((double)acc[u] * 512.0 / (double)norm_s);
                 v = v < 255.f ? v : 255.f;

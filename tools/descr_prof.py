@@ -22,3 +22,6 @@ with sift_amd.Context(1920, 1080, max_batch=B) as ctx:
     print(kind, "keypoints", int(ctx.counts().sum()))
     for n, v in zip(names, out):
         print(f"{n:12s} {v:14d} {100.0 * v / tot:5.1f}%")
+    nb = max(out[12], 1)
+    print(f"batches {out[12]}, samples per batch {out[15] / nb:.1f}, longest lane walk per batch {out[13] / nb:.2f} pairs, "
+          f"mean lane walk {out[14] / nb / 64:.2f} pairs")
