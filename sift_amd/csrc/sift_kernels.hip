@@ -50,9 +50,16 @@ __device__ __forceinline__ void buf_st2(__amdgpu_buffer_rsrc_t r, unsigned lane_
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, lane_bytes, row_bytes, 0);
 }
+// A 16-byte buffer store reads its data registers for a few cycles after it has issued.  The
+// compiler only separates such a store from a following write to those registers when the store has
+// no scalar offset register; with one (as here) it may place the overwrite directly behind the
+// store, and on gfx950 some lanes then store the new value (seen as wrong samples in every fourth
+// column).  The asm reads the four registers after the store, so nothing may overwrite them before
+// its wait states have passed; tests/test_abi.py scans the disassembly for the pattern.
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes, v4f v)
 {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, lane_bytes, row_bytes, 0);
+    asm volatile("s_nop 1" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 }
 
 #define SA_PI 3.14159265358979323846
@@ -273,7 +280,9 @@ extern "C" void sift_amd_debug_blur_clock(unsigned long long* out, int reset)
 // OVS = true: `in` is the input image (wi x hi) and the blurred source is its oversampled
 // version at step `delta`, evaluated on the fly (w x h is the oversampled size).
 
-template <int R, bool OVS, int EW, int NBUF, bool VW>
+// PREV = false: no DoG epilogue (dog and flags are null), the buffer of unfiltered centre samples
+// does not exist and a block needs half the LDS.
+template <int R, bool OVS, int EW, int NBUF, bool VW, bool PREV>
 __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
@@ -288,7 +297,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     __shared__ __attribute__((aligned(16))) float l_tmp[NBUF][G][PITCH];
-    __shared__ __attribute__((aligned(16))) float l_prev[NBUF][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float l_prev[PREV ? NBUF : 1][PREV ? G : 1][PREV ? PITCH : 4];
     const int tid = threadIdx.x;
     const unsigned vid = xcd_remap(blockIdx.x, nblocks);
     const int bx = vid % nbx, by = (vid / nbx) % nby;
@@ -443,7 +452,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 s = s + tp.g[k] * win_pair_sum(wp, g + R - k, g + R + k);
             l_tmp[buf][g][tid] = s.x;
             l_tmp[buf][g + 1][tid] = s.y;
-            if (dog || flags) {          // unfiltered centre samples, for the DoG epilogue
+            if (PREV) {                  // unfiltered centre samples, for the DoG epilogue
                 l_prev[buf][g][tid] = ctr.x;
                 l_prev[buf][g + 1][tid] = ctr.y;
             }
@@ -485,7 +494,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                             if (xo + q < w) buf_st1(r_out, loff + 4 * q, tile_off, o4[q]);
                     }
                 }
-                if (dog || flags) {
+                if (PREV) {
                     const v4f pv = ld4(&l_prev[buf][hg][RP + 4 * hq]);
                     const float d4[4] = {__fsub_rn(o4[0], pv.x), __fsub_rn(o4[1], pv.y),
                                          __fsub_rn(o4[2], pv.z), __fsub_rn(o4[3], pv.w)};
@@ -1720,16 +1729,25 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     float* out = a.out;
     SaTapPairs tp2;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
-#define SA_BLUR_LAUNCH(OVS_, VW_, ...)                                                                       \
-    HIPK((k_blur_fused<R, OVS_, EW, NBUF, VW_>), dim3(nblocks), dim3(EW), 0, st, a.in, out, a.dog, a.sub, a.w, a.h, \
+#define SA_BLUR_LAUNCH(OVS_, VW_, PREV_, ...)                                                                \
+    HIPK((k_blur_fused<R, OVS_, EW, NBUF, VW_, PREV_>), dim3(nblocks), dim3(EW), (OVS_ || PREV_ ? 0 : pad_np), st, a.in, out, a.dog, a.sub, a.w, a.h, \
          a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, __VA_ARGS__, a.flags, a.flag_thr)
     const bool vw = (a.w & 3) == 0;
-    if (a.ovs_w > 0) {
-        if (vw) SA_BLUR_LAUNCH(true, true, a.ovs_w, a.ovs_h, a.ovs_delta);
-        else SA_BLUR_LAUNCH(true, false, a.ovs_w, a.ovs_h, a.ovs_delta);
+    const bool prev = a.dog || a.flags;
+    // Occupancy (measured, 128 1080p images): the seed launch, whose loads interpolate, runs 12 % faster
+    // with three blocks per CU, which it gets without the centre-sample buffer (1.48 -> 1.29 ms);
+    // the plain launches are fastest with two (R = 5: 1.62 ms, 1.69 with three, 1.76 with four,
+    // 1.68 with one), so those without the buffer reserve its size as unused dynamic LDS.
+    constexpr int pad_np = NBUF * 8 * (EW + 32) * (int)sizeof(float);
+    if (a.ovs_w > 0 && !prev) {         // (the seed image has no DoG)
+        if (vw) SA_BLUR_LAUNCH(true, true, false, a.ovs_w, a.ovs_h, a.ovs_delta);
+        else SA_BLUR_LAUNCH(true, false, false, a.ovs_w, a.ovs_h, a.ovs_delta);
+    } else if (prev) {
+        if (vw) SA_BLUR_LAUNCH(false, true, true, 0, 0, 0.f);
+        else SA_BLUR_LAUNCH(false, false, true, 0, 0, 0.f);
     } else {
-        if (vw) SA_BLUR_LAUNCH(false, true, 0, 0, 0.f);
-        else SA_BLUR_LAUNCH(false, false, 0, 0, 0.f);
+        if (vw) SA_BLUR_LAUNCH(false, true, false, 0, 0, 0.f);
+        else SA_BLUR_LAUNCH(false, false, false, 0, 0, 0.f);
     }
 #undef SA_BLUR_LAUNCH
 }

@@ -83,8 +83,8 @@ def test_product_does_not_reference_the_oracle():
                 f"{path} refers to the test oracle"
 
 
-def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
-    """Disassembles the gfx950 code object embedded in the shipped library."""
+def _disassembly(tmp_path):
+    """Disassembles the gfx950 code objects embedded in the shipped library."""
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("llvm-objdump not available")
@@ -93,7 +93,41 @@ def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
     subprocess.check_call([objdump, "--offloading", so], stdout=subprocess.DEVNULL)
     cos = glob.glob(so + ".*gfx950*")
     assert cos, "no gfx950 code object in the library"
-    asm = "".join(subprocess.check_output([objdump, "-d", co]).decode() for co in cos)
+    return "".join(subprocess.check_output([objdump, "-d", co]).decode() for co in cos)
+
+
+def test_wide_buffer_stores_keep_their_data_registers(tmp_path):
+    """A 12/16-byte buffer store with a scalar offset register must not be followed directly by a
+    vector instruction that overwrites its data registers: on gfx950 part of the lanes then store
+    the new value, and the compiler does not separate the two by itself (buf_st4 in
+    sift_kernels.hip supplies the wait states)."""
+    asm = _disassembly(tmp_path)
+    current, prev_store, hits, n_stores = None, None, [], 0
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            current, prev_store = m.group(1), None
+            continue
+        ins = line.strip().split("//")[0].strip()
+        if not ins or not re.match(r"^[a-z]", ins):
+            continue
+        if prev_store is not None:
+            d = re.match(r"^v_(?!cmp|readlane|readfirstlane)\w+\s+(?:v\[(\d+):(\d+)\]|v(\d+))\b", ins)
+            if d:
+                lo, hi = (int(d.group(3)),) * 2 if d.group(3) else (int(d.group(1)), int(d.group(2)))
+                if lo <= prev_store[1] and hi >= prev_store[0]:
+                    hits.append((current, prev_store[2], ins))
+            prev_store = None
+        st = re.match(r"^buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],.*\bs\d+\s+offen", ins)
+        if st:
+            n_stores += 1
+            prev_store = (int(st.group(1)), int(st.group(2)), ins)
+    assert n_stores > 100, "no wide buffer stores found: the scan does not match the disassembly"
+    assert not hits, f"{len(hits)} wide buffer stores followed by an overwrite of their data, e.g. {hits[:3]}"
+
+
+def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
+    asm = _disassembly(tmp_path)
     # every kernel whose float arithmetic decides discrete extrema or refined positions
     families = ["k_blur_fused", "k_blur_v_any", "k_blur_h_any", "k_oversample", "k_subsample2", "k_sub",
                 "k_gradient", "k_extrema", "k_refine"]
