@@ -1016,7 +1016,7 @@ __device__ __forceinline__ float bin_to_ori(float bin, int nbins)   // lib_descr
 // lib_description.c:122-169 (accumulation), :406-423 (smoothing), :201-227 (peaks),
 // driver loops lib_sift_anatomy.c:599-681.  One wave per keypoint; lane p of a chunk handles
 // the p-th sample of the patch in raster order, lane b (< n_bins) owns histogram bin b and
-// adds the chunk's contributions to it in sample order.
+// adds the chunk's contributions to it in sample order (per-bin lists in LDS).
 // mode 0: every peak above t*max becomes a keypoint; mode 1: only the global maximum.
 __global__ void __launch_bounds__(64)
 k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const int* __restrict__ index,
@@ -1027,6 +1027,10 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
     const long long b = blockIdx.y;
     const int n = min(counters[b * SA_CNT_STRIDE + cnt_slot], icap);
     const int nbins = sc.n_bins;
+    extern __shared__ float ori_lds[];             // nbins * 65 list slots, then 64 counts
+    float* list_l = ori_lds;
+    int* cnt_l = reinterpret_cast<int*>(ori_lds + nbins * 65);
+    const unsigned long long lt = lanemask_lt();
     for (int q = blockIdx.x; q < n; q += gridDim.x) {
         const int src = index ? index[b * icap + q] : q;
         const SaKey key = keys[b * kcap + src];
@@ -1070,14 +1074,29 @@ k_orientation(SaPyramid P, SaScalars sc, const SaKey* __restrict__ keys, const i
             }
             fj += 64;
             while (fj >= nw) { fj -= nw; ++fi; }
-            // sample e's bin and magnitude reach the bin owners through scalar registers
-            // (v_readlane, no LDS traffic); lanes past the end of the patch hold bin -1
+            // The chunk's magnitudes go to LDS, one list per bin in sample order, and every bin
+            // owner adds its list.  A sample's place in its list is the number of earlier lanes
+            // with the same bin: the mask of those lanes is the intersection, over the six bits of
+            // the bin number, of the ballot of that bit or its complement.
+            const bool valid = bin >= 0;
+            unsigned long long same = __ballot(valid);
 #pragma unroll
-            for (int e = 0; e < 64; ++e) {
-                const int be = __builtin_amdgcn_readlane(bin, e);
-                const float Me = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(M), e));
-                if (be == lane) hb = __fadd_rn(hb, Me);
+            for (int i = 0; i < 6; ++i) {
+                const bool bit = (bin >> i) & 1;
+                const unsigned long long bi = __ballot(bit);
+                same &= bit ? bi : ~bi;
             }
+            cnt_l[lane] = 0;                       // (my own bin's count; one wave, LDS operations stay in order)
+            __syncthreads();
+            if (valid) {
+                list_l[bin * 65 + __popcll(same & lt)] = M;     // pitch 65: the owners' reads below hit 64 banks
+                cnt_l[bin] = __popcll(same);                    // the same value from every lane of the bin
+            }
+            __syncthreads();
+            const int mine = cnt_l[lane];
+            for (int r = 0; __ballot(r < mine); ++r)
+                if (r < mine) hb = __fadd_rn(hb, list_l[lane * 65 + r]);
+            __syncthreads();
         }
         // six circular box passes
         for (int it = 0; it < 6; ++it) {
@@ -1871,7 +1890,7 @@ void launch_orientation(hipStream_t st, const SaPyramid& P, const SaScalars& sc,
                         const int* index, const int* counters, int cnt_slot, int kcap, int icap, int mode,
                         int* ori_n, float* ori_theta, float* ori_hist, int batch)
 {
-    HIPK(k_orientation, dim3(2048, batch), dim3(64), 0, st, P, sc, keys, index, counters, cnt_slot,
+    HIPK(k_orientation, dim3(2048, batch), dim3(64), (size_t)(sc.n_bins * 65 + 64) * sizeof(float), st, P, sc, keys, index, counters, cnt_slot,
          kcap, icap, mode, ori_n, ori_theta, ori_hist);
 }
 
