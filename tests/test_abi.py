@@ -122,6 +122,24 @@ def test_wide_buffer_stores_keep_their_data_registers(tmp_path):
         if st:
             n_stores += 1
             prev_store = (int(st.group(1)), int(st.group(2)), ins)
+    # the other hazard the compiler leaves to hand-written code here: v_writelane_b32 reading an
+    # SGPR in the cycle after the vector compare that wrote it (masks_to_lanes* in sift_kernels.hip,
+    # probe: tools/membench/writelane_test.hip)
+    prev, n_wl = "", 0
+    for line in asm.splitlines():
+        ins = line.strip().split("//")[0].strip()
+        if not ins or not re.match(r"^[a-z]", ins):
+            continue
+        if ins.startswith("v_writelane_b32"):
+            n_wl += 1
+            src = re.match(r"^v_writelane_b32 v\d+, (s(\d+)|vcc_lo|vcc_hi)", ins)
+            dst = re.match(r"^v_cmp\w+ (s\[(\d+):(\d+)\]|vcc)", prev)
+            if src and dst:
+                same = (dst.group(1) == "vcc") == src.group(1).startswith("vcc") and \
+                       (src.group(1).startswith("vcc") or int(dst.group(2)) <= int(src.group(2)) <= int(dst.group(3)))
+                assert not same, f"v_writelane_b32 reads what the compare directly before it wrote: {prev} / {ins}"
+        prev = ins
+    assert n_wl >= 36, "the ballot-to-lane writes of the descriptor kernel are not in the disassembly"
     assert n_stores > 100, "no wide buffer stores found: the scan does not match the disassembly"
     assert not hits, f"{len(hits)} wide buffer stores followed by an overwrite of their data, e.g. {hits[:3]}"
 
