@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 
 #include "../../include/sift_amd.h"
@@ -50,10 +51,23 @@ struct ThreadCache {
     float* d_grad = nullptr;
     size_t grad_floats = 0;
     int grad_device = -1;
+    // pinned staging of the scale-space downloads (two halves used in turn) and their stream
+    char* pin = nullptr;
+    hipStream_t copy_stream = nullptr;
+    int copy_device = -1;
     void release()
     {
         for (auto& c : e)
             if (c.ctx) { sift_amd_destroy(c.ctx); c.ctx = nullptr; }
+        if (pin) { (void)hipHostFree(pin); pin = nullptr; }
+        if (copy_stream) {
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            (void)hipSetDevice(copy_device);
+            (void)hipStreamDestroy(copy_stream);
+            if (prev >= 0) (void)hipSetDevice(prev);
+            copy_stream = nullptr;
+        }
         if (d_grad) {
             int prev = -1;
             (void)hipGetDevice(&prev);
@@ -294,11 +308,75 @@ static struct keypoint* key_from_record(const sift_amd_key& r, const sift_parame
     return k;
 }
 
+// Device memory into a freshly malloc'd (pageable, not yet touched) host block.  A plain hipMemcpy
+// spends most of its time in the page faults of the destination; here the bytes arrive in pinned
+// staging memory, 32 MB at a time, and a few host threads copy each piece to its place (and take
+// the page faults side by side) while the next piece is on its way.
+static void download_to_pageable(void* dst, const void* d_src, size_t bytes)
+{
+    constexpr size_t CH = 32u << 20;
+    if (bytes < (4u << 20)) {
+        if (hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) != hipSuccess) die("download");
+        return;
+    }
+    ThreadCache& tc = g_cache;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (tc.copy_stream && tc.copy_device != dev) { (void)hipStreamDestroy(tc.copy_stream); tc.copy_stream = nullptr; }
+    if (!tc.copy_stream) {
+        if (hipStreamCreateWithFlags(&tc.copy_stream, hipStreamNonBlocking) != hipSuccess) die("download stream");
+        tc.copy_device = dev;
+    }
+    if (!tc.pin && hipHostMalloc((void**)&tc.pin, 2 * CH, hipHostMallocDefault) != hipSuccess) die("pinned staging");
+    static const unsigned n_thr = [] {
+        const char* e = getenv("SIFT_AMD_COPY_THREADS");
+        unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        return n < 1 ? 1u : (n > 8 ? 8u : n);
+    }();
+    auto issue = [&](size_t off, int half) {
+        const size_t n = std::min(CH, bytes - off);
+        if (hipMemcpyAsync(tc.pin + half * CH, (const char*)d_src + off, n, hipMemcpyDeviceToHost, tc.copy_stream) != hipSuccess)
+            die("download");
+    };
+    issue(0, 0);
+    int half = 0;
+    for (size_t off = 0; off < bytes; off += CH, half ^= 1) {
+        if (hipStreamSynchronize(tc.copy_stream) != hipSuccess) die("download");
+        if (off + CH < bytes) issue(off + CH, half ^ 1);
+        const size_t n = std::min(CH, bytes - off);
+        const size_t per = ((n + n_thr - 1) / n_thr + 4095) & ~(size_t)4095;
+        std::vector<std::thread> workers;
+        char* to = (char*)dst + off;
+        const char* from = tc.pin + half * CH;
+        for (unsigned t = 1; t < n_thr && t * per < n; t++) {
+            const size_t at = t * per, len = std::min(per, n - at);
+            workers.emplace_back([to, from, at, len] { memcpy(to + at, from + at, len); });
+        }
+        memcpy(to, from, std::min(per, n));
+        for (auto& w : workers) w.join();
+    }
+}
+
+struct DeviceScope {     // the reference-named calls run on SIFT_AMD_DEVICE and leave the caller's device as it was
+    int prev = -1;
+    explicit DeviceScope(int dev) { (void)hipGetDevice(&prev); if (hipSetDevice(dev) != hipSuccess) { sa_set_error("hipSetDevice failed"); die("device"); } }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 static void download_stack(sift_amd_ctx* c, int which, struct sift_scalespace* ss)
 {
-    for (int o = 0; o < ss->nOct; o++)
-        if (sift_amd_copy_scalespace(c, 0, which, o, ss->octaves[o]->imStack)) die("copy scale-space");
+    DeviceScope on(env_device());
+    for (int o = 0; o < ss->nOct; o++) {
+        const struct octa* oc = ss->octaves[o];
+        const float* d = sa_ctx_stack(c, which, o);
+        if (!d) die("copy scale-space");
+        download_to_pageable(oc->imStack, d, (size_t)oc->nSca * oc->w * oc->h * sizeof(float));
+    }
 }
+
+// ss[2], ss[3] of sift_anatomy (lib_sift_anatomy.c:202-218, 842-844) from the Gaussian stack that
+// is still on the device.
+static void gradient_stacks_from_ctx(sift_amd_ctx* c, struct sift_scalespace* sx, struct sift_scalespace* sy);
 
 // d/di and d/dj of every image of a host scale-space (lib_sift_anatomy.c:202-218).  The device
 // scratch (one stack in, two out, sized for the largest octave) is kept per host thread.
@@ -331,6 +409,35 @@ static void gradient_stacks(const struct sift_scalespace* s, struct sift_scalesp
         if (!ok) { sa_set_error("gradient transfer failed: %s", hipGetErrorString(hipGetLastError())); die("gradient"); }
     }
     if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+}
+
+static void gradient_stacks_from_ctx(sift_amd_ctx* c, struct sift_scalespace* sx, struct sift_scalespace* sy)
+{
+    const int dev = env_device();
+    DeviceScope on(dev);
+    size_t biggest = 0;
+    for (int o = 0; o < sx->nOct; o++) {
+        const struct octa* oc = sx->octaves[o];
+        biggest = std::max(biggest, (size_t)oc->nSca * oc->w * oc->h);
+    }
+    ThreadCache& tc = g_cache;
+    if (tc.grad_floats < biggest || tc.grad_device != dev) {
+        if (tc.d_grad) { (void)hipSetDevice(tc.grad_device); (void)hipFree(tc.d_grad); (void)hipSetDevice(dev); }
+        tc.d_grad = nullptr; tc.grad_floats = 0;
+        if (hipMalloc((void**)&tc.d_grad, 3 * biggest * sizeof(float)) != hipSuccess) { sa_set_error("hipMalloc failed"); die("gradient"); }
+        tc.grad_floats = biggest; tc.grad_device = dev;
+    }
+    float *d_gi = tc.d_grad + tc.grad_floats, *d_gj = tc.d_grad + 2 * tc.grad_floats;
+    for (int o = 0; o < sx->nOct; o++) {
+        const struct octa* oc = sx->octaves[o];
+        const float* d = sa_ctx_stack(c, 0, o);
+        if (!d) die("gradient");
+        sa::launch_gradient(nullptr, d, d_gi, d_gj, oc->w, oc->h, oc->nSca);
+        if (hipStreamSynchronize(nullptr) != hipSuccess) die("gradient");
+        const size_t bytes = (size_t)oc->nSca * oc->w * oc->h * sizeof(float);
+        download_to_pageable(sx->octaves[o]->imStack, d_gi, bytes);
+        download_to_pageable(sy->octaves[o]->imStack, d_gj, bytes);
+    }
 }
 
 // ---------------------------------------------------------- reference API --
@@ -382,7 +489,7 @@ static struct sift_keypoints* run_full(const float* x, int w, int h, const sift_
     if (n_ss == 4) {
         ss[2] = scalespace_from_layout(L, 0);
         ss[3] = scalespace_from_layout(L, 0);
-        gradient_stacks(ss[0], ss[2], ss[3]);
+        gradient_stacks_from_ctx(c, ss[2], ss[3]);
     }
 
     // stage lists, in canonical order

@@ -35,3 +35,5 @@ float* sa_ctx_input_buffer(sift_amd_ctx* c);
 // device records of the final keypoints of one image of the last run (waits for it)
 int sa_ctx_image_keys(sift_amd_ctx* c, int img, const void** d_std, const float** d_descr, int* n, int* n_descr);
 hipStream_t sa_ctx_stream(sift_amd_ctx* c);
+// device address of image 0's Gaussian (which = 0) or DoG (1) stack of octave o; waits for the last run
+const float* sa_ctx_stack(sift_amd_ctx* c, int which, int o);

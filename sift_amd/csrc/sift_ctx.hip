@@ -1157,3 +1157,10 @@ const SaLayout* sa_ctx_layout(const sift_amd_ctx* c) { return &c->L; }
 const sift_parameters* sa_ctx_params(const sift_amd_ctx* c) { return &c->p; }
 float* sa_ctx_input_buffer(sift_amd_ctx* c) { return c->d_in; }
 hipStream_t sa_ctx_stream(sift_amd_ctx* c) { return c->own_stream; }
+const float* sa_ctx_stack(sift_amd_ctx* c, int which, int o)
+{
+    if (o < 0 || o >= c->L.n_oct || which < 0 || which > 1 || (which == 1 && !c->d_dog[o])) return nullptr;
+    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    return which == 0 ? c->d_gss[o] : c->d_dog[o];
+}
