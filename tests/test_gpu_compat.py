@@ -1,6 +1,7 @@
 """GPU: the remaining reference-named entry points (flat lib_sift.h API, description-only
 variants, stand-alone scale-space), called through ctypes exactly as C host code would."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -302,3 +303,38 @@ def test_alternating_reference_named_calls_keep_their_contexts(hip):
             assert same_bits(gss[o]["stack"], want["gss"][o])
     print("rounds:", times)
     hip.sift_amd_release_thread_cache()
+
+
+def test_scale_spaces_of_sift_anatomy_with_other_copy_thread_counts(hip):
+    """The four scale-spaces sift_anatomy() hands back travel through pinned staging in 32 MB pieces
+    that several host threads copy into place; one thread, and a count that does not divide the
+    pieces evenly, must give the same bytes as the oracle (stacks large enough for two pieces)."""
+    img = synth.make("white", 700, 500, 31)
+    want = pyoracle.run(img, keep_ss=True)
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import sift_amd\n"
+        "from sift_amd import synth\n"
+        "from oracle import refrun\n"
+        "got = refrun.run_sift_anatomy(sift_amd.lib(), synth.make('white', 700, 500, 31))\n"
+        "for k in ('gss', 'dog', 'gx', 'gy'):\n"
+        "    print(k, ' '.join(hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() for a in got[k]))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import hashlib
+    import subprocess
+    import sys
+    expected = {"gss": want["gss"], "dog": want["dog"]}
+    grads = []
+    for n in ("1", "3"):
+        env = dict(os.environ, SIFT_AMD_COPY_THREADS=n)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+        assert out.returncode == 0, out.stderr[-1500:]
+        lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines() if l[:3] in ("gss", "dog", "gx ", "gy "))
+        for k, stacks in expected.items():
+            digests = [hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() for a in stacks]
+            assert lines[k].split() == digests, f"{k} differs with {n} copy thread(s)"
+        grads.append((lines["gx"].split(), lines["gy"].split()))
+    here = refrun.run_sift_anatomy(hip, img)          # this process: default thread count
+    mine = tuple([hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() for a in here[k]] for k in ("gx", "gy"))
+    assert grads[0] == grads[1] == mine and len(mine[0]) == len(want["gss"])
