@@ -308,6 +308,27 @@ static struct keypoint* key_from_record(const sift_amd_key& r, const sift_parame
     return k;
 }
 
+// The calling thread's own non-blocking stream on the current device (the library stays off the
+// legacy default stream: its implicit synchronisation fails while another host thread captures a
+// hipGraph).
+static hipStream_t thread_stream()
+{
+    ThreadCache& tc = g_cache;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (tc.copy_stream && tc.copy_device != dev) { (void)hipStreamDestroy(tc.copy_stream); tc.copy_stream = nullptr; }
+    if (!tc.copy_stream) {
+        if (hipStreamCreateWithFlags(&tc.copy_stream, hipStreamNonBlocking) != hipSuccess) die("thread stream");
+        tc.copy_device = dev;
+    }
+    return tc.copy_stream;
+}
+static bool copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    hipStream_t st = thread_stream();
+    return hipMemcpyAsync(dst, src, bytes, kind, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+}
+
 // Device memory into a freshly malloc'd (pageable, not yet touched) host block.  A plain hipMemcpy
 // spends most of its time in the page faults of the destination; here the bytes arrive in pinned
 // staging memory, 32 MB at a time, and a few host threads copy each piece to its place (and take
@@ -316,17 +337,11 @@ static void download_to_pageable(void* dst, const void* d_src, size_t bytes)
 {
     constexpr size_t CH = 32u << 20;
     if (bytes < (4u << 20)) {
-        if (hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) != hipSuccess) die("download");
+        if (!copy_sync(dst, d_src, bytes, hipMemcpyDeviceToHost)) die("download");
         return;
     }
     ThreadCache& tc = g_cache;
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    if (tc.copy_stream && tc.copy_device != dev) { (void)hipStreamDestroy(tc.copy_stream); tc.copy_stream = nullptr; }
-    if (!tc.copy_stream) {
-        if (hipStreamCreateWithFlags(&tc.copy_stream, hipStreamNonBlocking) != hipSuccess) die("download stream");
-        tc.copy_device = dev;
-    }
+    (void)thread_stream();
     if (!tc.pin && hipHostMalloc((void**)&tc.pin, 2 * CH, hipHostMallocDefault) != hipSuccess) die("pinned staging");
     static const unsigned n_thr = [] {
         const char* e = getenv("SIFT_AMD_COPY_THREADS");
@@ -402,10 +417,10 @@ static void gradient_stacks(const struct sift_scalespace* s, struct sift_scalesp
     for (int o = 0; o < s->nOct; o++) {
         const struct octa* oc = s->octaves[o];
         const size_t bytes = (size_t)oc->nSca * oc->w * oc->h * 4;
-        bool ok = hipMemcpy(d_im, oc->imStack, bytes, hipMemcpyHostToDevice) == hipSuccess;
-        sa::launch_gradient(nullptr, d_im, d_gi, d_gj, oc->w, oc->h, oc->nSca);
-        ok = ok && hipMemcpy(sx->octaves[o]->imStack, d_gi, bytes, hipMemcpyDeviceToHost) == hipSuccess;
-        ok = ok && hipMemcpy(sy->octaves[o]->imStack, d_gj, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+        bool ok = copy_sync(d_im, oc->imStack, bytes, hipMemcpyHostToDevice);
+        sa::launch_gradient(thread_stream(), d_im, d_gi, d_gj, oc->w, oc->h, oc->nSca);
+        ok = ok && copy_sync(sx->octaves[o]->imStack, d_gi, bytes, hipMemcpyDeviceToHost);
+        ok = ok && copy_sync(sy->octaves[o]->imStack, d_gj, bytes, hipMemcpyDeviceToHost);
         if (!ok) { sa_set_error("gradient transfer failed: %s", hipGetErrorString(hipGetLastError())); die("gradient"); }
     }
     if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
@@ -432,8 +447,8 @@ static void gradient_stacks_from_ctx(sift_amd_ctx* c, struct sift_scalespace* sx
         const struct octa* oc = sx->octaves[o];
         const float* d = sa_ctx_stack(c, 0, o);
         if (!d) die("gradient");
-        sa::launch_gradient(nullptr, d, d_gi, d_gj, oc->w, oc->h, oc->nSca);
-        if (hipStreamSynchronize(nullptr) != hipSuccess) die("gradient");
+        sa::launch_gradient(thread_stream(), d, d_gi, d_gj, oc->w, oc->h, oc->nSca);
+        if (hipStreamSynchronize(thread_stream()) != hipSuccess) die("gradient");
         const size_t bytes = (size_t)oc->nSca * oc->w * oc->h * sizeof(float);
         download_to_pageable(sx->octaves[o]->imStack, d_gi, bytes);
         download_to_pageable(sy->octaves[o]->imStack, d_gj, bytes);

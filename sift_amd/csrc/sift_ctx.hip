@@ -216,6 +216,17 @@ struct sift_amd_ctx {
     long long prof_blur_n[SA_MAX_OCT][SA_MAX_SCA] = {};
 };
 
+// Blocking copy on the context's own (non-blocking) stream.  The library never uses the legacy
+// default stream: a plain hipMemcpy from one host thread fails with "operation would make the legacy
+// stream depend on a capturing blocking stream" whenever another host thread happens to be capturing a
+// hipGraph at that moment, even in thread-local capture mode and on non-blocking streams.
+static hipError_t sa_copy(sift_amd_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    if (!bytes) return hipSuccess;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->own_stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(c->own_stream);
+}
+
 template <typename T>
 static int dev_alloc(sift_amd_ctx* c, T** p, size_t count)
 {
@@ -247,7 +258,7 @@ static int make_blur(sift_amd_ctx* c, BlurSpec* b, float sigma)
             return -1;
         }
         if (dev_alloc(c, &b->taps_dev, g.size())) return -1;
-        HIP_TRY(hipMemcpy(b->taps_dev, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(sa_copy(c, b->taps_dev, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -427,7 +438,8 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
 {
     if (!c) return;
     DeviceGuard dev_guard_(c->device);
-    hipDeviceSynchronize();
+    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& e : c->prof_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : c->prof_pool) hipEventDestroy(e);
     for (auto* g : c->graphs) {
@@ -794,7 +806,7 @@ extern "C" int sift_amd_copy_ingested(sift_amd_ctx* c, int n, float* dst)
     SA_ON_DEVICE(c);
     hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(dst, c->d_in, (size_t)n * c->im_w * c->im_h * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(sa_copy(c, dst, c->d_in, (size_t)n * c->im_w * c->im_h * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -850,9 +862,9 @@ extern "C" int sift_amd_fetch_keypoints(sift_amd_ctx* c, int img, sift_keypoint_
     if (sa_sync_counters(c)) return -1;
     int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS], max_keys);
     if (n > 0 && out_std)
-        HIP_TRY(hipMemcpy(out_std, c->d_std + (size_t)img * c->kcap, (size_t)n * sizeof(SaStd), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, out_std, c->d_std + (size_t)img * c->kcap, (size_t)n * sizeof(SaStd), hipMemcpyDeviceToHost));
     if (n > 0 && out_keys)
-        HIP_TRY(hipMemcpy(out_keys, c->d_keys + (size_t)img * c->kcap, (size_t)n * sizeof(SaKey), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, out_keys, c->d_keys + (size_t)img * c->kcap, (size_t)n * sizeof(SaKey), hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -1028,10 +1040,10 @@ extern "C" int sift_amd_fetch_candidates(sift_amd_ctx* c, int img, sift_amd_key*
     std::vector<SaKey> ref(n);
     std::vector<int> stg(n);
     if (n) {
-        HIP_TRY(hipMemcpy(key.data(), c->d_ckey + (size_t)img * c->cap, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(val.data(), c->d_cval + (size_t)img * c->cap, n * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(ref.data(), c->d_ref + (size_t)img * c->cap, n * sizeof(SaKey), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(stg.data(), c->d_stage + (size_t)img * c->cap, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, key.data(), c->d_ckey + (size_t)img * c->cap, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, val.data(), c->d_cval + (size_t)img * c->cap, n * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, ref.data(), c->d_ref + (size_t)img * c->cap, n * sizeof(SaKey), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, stg.data(), c->d_stage + (size_t)img * c->cap, n * sizeof(int), hipMemcpyDeviceToHost));
     }
     // canonical order = ascending packed (o,s,i,j) of the seed; keys are unique
     std::vector<int> order(n);
@@ -1070,7 +1082,7 @@ extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int
     const long long np = (long long)c->L.w[o] * c->L.h[o];
     const int nimg = which == 0 ? c->L.n_sca : c->L.n_sca - 1;
     const float* src = (which == 0 ? c->d_gss[o] : c->d_dog[o]) + (long long)img * nimg * np;
-    HIP_TRY(hipMemcpy(dst, src, (size_t)(nimg * np) * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(sa_copy(c, dst, src, (size_t)(nimg * np) * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1083,15 +1095,15 @@ extern "C" int sift_amd_fetch_extras(sift_amd_ctx* c, int img, float* orihist, f
     const int nb = c->p.n_bins, nd = c->p.n_hist * c->p.n_hist * c->p.n_ori;
     if (n && descr) {
         std::vector<float> tmp((size_t)n * SA_MAX_DESCR);
-        HIP_TRY(hipMemcpy(tmp.data(), c->d_descr + (size_t)img * c->kcap * SA_MAX_DESCR, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, tmp.data(), c->d_descr + (size_t)img * c->kcap * SA_MAX_DESCR, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (int k = 0; k < n; k++) memcpy(descr + (size_t)k * nd, tmp.data() + (size_t)k * SA_MAX_DESCR, nd * sizeof(float));
     }
     if (n && (orihist || src_index)) {
         const int nf = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_NF], c->fcap);
         std::vector<float> hist((size_t)std::max(nf, 1) * SA_MAX_BINS);
         std::vector<int> src(n);
-        HIP_TRY(hipMemcpy(hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, (size_t)nf * SA_MAX_BINS * sizeof(float), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(src.data(), c->d_key_src + (size_t)img * c->kcap, n * sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, (size_t)nf * SA_MAX_BINS * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, src.data(), c->d_key_src + (size_t)img * c->kcap, n * sizeof(int), hipMemcpyDeviceToHost));
         for (int k = 0; k < n; k++) {
             if (orihist) memcpy(orihist + (size_t)k * nb, hist.data() + (size_t)src[k] * SA_MAX_BINS, nb * sizeof(float));
             if (src_index) src_index[k] = src[k];
@@ -1108,7 +1120,7 @@ extern "C" int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* c, int img, float
     const int nb = c->p.n_bins;
     if (nf && orihist) {
         std::vector<float> hist((size_t)nf * SA_MAX_BINS);
-        HIP_TRY(hipMemcpy(hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, hist.size() * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(sa_copy(c, hist.data(), c->d_ori_hist + (size_t)img * c->fcap * SA_MAX_BINS, hist.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (int k = 0; k < nf; k++) memcpy(orihist + (size_t)k * nb, hist.data() + (size_t)k * SA_MAX_BINS, nb * sizeof(float));
     }
     return nf;
@@ -1127,12 +1139,12 @@ int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orien
     int cnt[SA_CNT_STRIDE] = {0};
     cnt[SA_CNT_NF] = n; cnt[SA_CNT_KEYS] = n;
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipMemcpy(c->d_counters, cnt, sizeof cnt, hipMemcpyHostToDevice));
+    HIP_TRY(sa_copy(c, c->d_counters, cnt, sizeof cnt, hipMemcpyHostToDevice));
     if (find_orientation) {
-        if (n) HIP_TRY(hipMemcpy(c->d_given, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
+        if (n) HIP_TRY(sa_copy(c, c->d_given, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
         if (sa_run_orient(c, 1, st, true, 1)) return -1;
     } else {
-        if (n) HIP_TRY(hipMemcpy(c->d_keys, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
+        if (n) HIP_TRY(sa_copy(c, c->d_keys, keys, (size_t)n * sizeof(SaKey), hipMemcpyHostToDevice));
     }
     if (sa_run_describe(c, 1, st)) return -1;
     HIP_TRY(hipStreamSynchronize(st));

@@ -394,9 +394,16 @@ int match_host(int device, bool is_u8, const void* h1, int n1, const void* h2, i
     const size_t el = is_u8 ? 1 : sizeof(float);
     DevBuf a, b;
     if (a.alloc((size_t)n1 * dim * el) || b.alloc((size_t)n2 * dim * el)) return -1;
-    HIP_TRY(hipMemcpy(a.p, h1, (size_t)n1 * dim * el, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b.p, h2, (size_t)n2 * dim * el, hipMemcpyHostToDevice));
-    return match_device(nullptr, is_u8, a.p, dim, n1, b.p, dim, n2, dim, thresh, flag, iA, iB, dA, dB, pass);
+    // a stream of the call's own, not the legacy default stream (whose implicit synchronisation
+    // fails while another host thread captures a hipGraph)
+    struct LocalStream {
+        hipStream_t s = nullptr;
+        ~LocalStream() { if (s) (void)hipStreamDestroy(s); }
+    } ls;
+    HIP_TRY(hipStreamCreateWithFlags(&ls.s, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(a.p, h1, (size_t)n1 * dim * el, hipMemcpyHostToDevice, ls.s));
+    HIP_TRY(hipMemcpyAsync(b.p, h2, (size_t)n2 * dim * el, hipMemcpyHostToDevice, ls.s));
+    return match_device(ls.s, is_u8, a.p, dim, n1, b.p, dim, n2, dim, thresh, flag, iA, iB, dA, dB, pass);
 }
 
 }  // namespace
