@@ -198,6 +198,7 @@ struct sift_amd_ctx {
     };
     bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
     bool use_cells = true;          // SIFT_AMD_CELLS=0: the extrema scan visits every sample
+    bool use_pairs = true;          // SIFT_AMD_PAIR=0: every blur is a launch of its own
     std::vector<GraphEntry*> graphs;
     // keys launched eagerly once: a graph is built when a key comes back, so callers that pass a
     // new buffer every time do not pay a capture per call
@@ -305,6 +306,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     auto fail = [&]() -> sift_amd_ctx* { sift_amd_destroy(c); return nullptr; };
     if (const char* m = getenv("SIFT_AMD_GRAPH")) c->use_graph = atoi(m) != 0;
     if (const char* m = getenv("SIFT_AMD_CELLS")) c->use_cells = atoi(m) != 0;
+    if (const char* m = getenv("SIFT_AMD_PAIR")) c->use_pairs = atoi(m) != 0;
 
     for (int o = 1; o < L->n_oct; o++)
         if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
@@ -605,8 +607,31 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
             }
             // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
+            auto marked = [&](int sc) { return mark && sc - 1 >= 1 && sc - 1 <= ns - 3; };
+            auto emits_next_octave = [&](int sc) { return sc == ns - 3 && o + 1 < L.n_oct; };
+            // images s and s+1 in one launch where an instantiation exists (image s is then
+            // written but not read back); not for contexts that store DoG images
+            if (c->use_pairs && !d && s + 1 < ns && !emits_next_octave(s) && !emits_next_octave(s + 1) &&
+                !(marked(s) && marked(s + 1))) {
+                sa::BlurPairArgs pa;
+                pa.in = g + (s - 1) * np; pa.out_a = g + s * np; pa.out_b = g + (s + 1) * np;
+                pa.s_in = pa.s_a = pa.s_b = sg;
+                pa.w = L.w[o]; pa.h = L.h[o]; pa.batch = n;
+                pa.radius_a = c->step[o][s].radius; pa.radius_b = c->step[o][s + 1].radius;
+                pa.taps_a = c->step[o][s].taps; pa.taps_b = c->step[o][s + 1].taps;
+                pa.flag_on_a = marked(s); pa.flag_on_b = marked(s + 1);
+                pa.flags = (pa.flag_on_a || pa.flag_on_b) ? c->d_cells[o] : nullptr;
+                pa.flag_thr = c->sc.thr_pre;
+                if (sa::launch_blur_pair(st, pa, true)) {
+                    // (timed under the second image of the pair)
+                    ProfScope ps(c, st, SIFT_AMD_K_BLUR_FUSED, o, s + 1);
+                    sa::launch_blur_pair(st, pa);
+                    ++s;
+                    continue;
+                }
+            }
             int* cells = nullptr;
-            if (mark && s - 1 >= 1 && s - 1 <= ns - 3) {
+            if (marked(s)) {
                 if (c->step[o][s].radius >= 1 && c->step[o][s].radius <= SA_MAX_RADIUS_FAST) cells = c->d_cells[o];
                 else c->cells_valid[o] = false;
             }

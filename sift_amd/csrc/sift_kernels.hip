@@ -539,6 +539,213 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #endif
 }
 
+// ------------------------------------------------- two blurs in one launch --
+// Two successive blurs of an octave (image s-1 -> s -> s+1) in one launch, so that image s is
+// written but never read back: 12 instead of 16 bytes per pixel.  A block of 1024 threads has two
+// roles of 8 waves each.  The producer is the fused blur above (source rows from global memory,
+// column pass in registers, row pass through LDS) and also leaves its output rows, 8 per iteration,
+// in an LDS ring; the consumer runs the same two passes with radius RB on the rows it takes from the
+// ring.  Both roles share one barrier per iteration: the producer fills ring slot j&1 behind barrier
+// j, the consumer reads it behind barrier j+1 and uses it in iteration j+2, so the consumer trails by
+// 16 + RB rows and warms up for MB = 2 + ceil(RB/4) iterations before its window is complete.  Rows
+// and columns outside the image are produced at their mirrored positions, which gives the bits of the
+// mirrored result (the taps are symmetric and the pair sums commute).  A tile is 512 columns wide:
+// the producer's results are valid on 512 - 2 HA of them, the consumer's on 512 - 2 (HA + HB), the
+// columns a block stores (HA, HB: the radii rounded up to a multiple of 4).
+namespace pairk {
+constexpr int G = 8, EW = 512, PITCH = EW + 32;
+struct Geo {
+    int w, h;
+    int X0;                 // global column of tile-local column 0
+    int keep_lo, keep_hi;   // global columns this block stores
+    int i0, i1;             // rows this block stores
+    int n_iter;             // iterations of both roles
+    int cells_w;            // marks per row of 8 x 64 cells
+};
+
+// 4 outputs from a window of 4 + 2H column-filtered samples starting at lrow (16-byte aligned)
+template <int R, int H>
+__device__ __forceinline__ void row_item(const float* lrow, const SaTapPairs& tp, float (&o4)[4])
+{
+    v2f hp[(4 + 2 * H) / 2];
+#pragma unroll
+    for (int q = 0; q < (4 + 2 * H) / 4; ++q) {
+        const v4f v = ld4(lrow + 4 * q);
+        hp[2 * q] = v2f{v.x, v.y};
+        hp[2 * q + 1] = v2f{v.z, v.w};
+    }
+    v2f o01 = hp[H / 2] * tp.g[0], o23 = hp[H / 2 + 1] * tp.g[0];
+#pragma unroll
+    for (int k = 1; k <= R; ++k) {
+        o01 = o01 + tp.g[k] * win_pair_sum(hp, H - k, H + k);
+        o23 = o23 + tp.g[k] * win_pair_sum(hp, H + 2 - k, H + 2 + k);
+    }
+    o4[0] = o01.x; o4[1] = o01.y; o4[2] = o23.x; o4[3] = o23.y;
+}
+
+// column pass of one iteration: 8 outputs of column tid from the register window
+template <int R, bool PREV>
+__device__ __forceinline__ void col_pass(const v2f* wp, const SaTapPairs& tp, float (*tmp)[PITCH], float (*prev)[PITCH], int tid)
+{
+#pragma unroll
+    for (int g = 0; g < G; g += 2) {
+        const v2f ctr = win_pair(wp, g + R);
+        v2f s = ctr * tp.g[0];
+#pragma unroll
+        for (int k = 1; k <= R; ++k) s = s + tp.g[k] * win_pair_sum(wp, g + R - k, g + R + k);
+        tmp[g][tid] = s.x;
+        tmp[g + 1][tid] = s.y;
+        if (PREV) { prev[g][tid] = ctr.x; prev[g + 1][tid] = ctr.y; }
+    }
+}
+
+// stores 4 results (and, with PREV, the contrast mark of their cell)
+template <bool PREV>
+__device__ __forceinline__ void emit(const Geo& g, __amdgpu_buffer_rsrc_t r_out, __amdgpu_buffer_rsrc_t r_flags,
+                                     const float (&o4)[4], const float* prev4, float flag_thr, int row, int xo)
+{
+    buf_st4(r_out, (unsigned)(row * g.w + xo) * 4u, 0u, v4f{o4[0], o4[1], o4[2], o4[3]});
+    if (PREV) {
+        const v4f pv = ld4(prev4);
+        const float m = fmaxf(fmaxf(fabsf(__fsub_rn(o4[0], pv.x)), fabsf(__fsub_rn(o4[1], pv.y))),
+                              fmaxf(fabsf(__fsub_rn(o4[2], pv.z)), fabsf(__fsub_rn(o4[3], pv.w))));
+        if (m > flag_thr)
+            __builtin_amdgcn_raw_buffer_store_b32(1u, r_flags, (unsigned)((row >> 3) * g.cells_w + (xo >> 6)) * 4u, 0u, 0);
+    }
+}
+
+template <int R, int HA, int HB, bool PREV>
+__device__ __forceinline__ void producer(const float* in_img, float* out_img, int* flags_img, const SaTapPairs& tp, float flag_thr,
+                                         const Geo& g, int r0, int tid, float (*l_tmp)[G][PITCH], float (*l_prev)[G][PITCH],
+                                         float (*ring)[G][PITCH])
+{
+    constexpr int NG = (EW - 2 * HA) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
+    const __amdgpu_buffer_rsrc_t src = buf_rsrc(in_img), r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img);
+    const unsigned ucol = (unsigned)mirror_idx(g.X0 + tid, g.w) * 4u;
+    auto load = [&](int i) -> float { return buf_ld(src, ucol, (unsigned)(mirror_idx(i, g.h) * g.w) * 4u); };
+    v2f wp[NP];
+    float nx[G];
+    {
+        float pro[2 * R];
+#pragma unroll
+        for (int t = 0; t < 2 * R; ++t) pro[t] = load(r0 - R + t);
+#pragma unroll
+        for (int t = 0; t < R; ++t) wp[t] = v2f{pro[2 * t], pro[2 * t + 1]};
+    }
+#pragma unroll
+    for (int q = 0; q < G; ++q) nx[q] = load(r0 + R + q);
+    int buf = 0;
+    for (int j = 0; j < g.n_iter; ++j, buf ^= 1) {
+        const int ii = r0 + G * j;
+        // the rows of the last two iterations would reach the consumer after its last iteration
+        const bool work = j + 2 < g.n_iter;
+#pragma unroll
+        for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
+        if (j + 3 < g.n_iter) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) nx[q] = load(ii + G + R + q);
+        }
+        if (work) col_pass<R, PREV>(wp, tp, l_tmp[buf], l_prev[PREV ? buf : 0], tid);
+        __syncthreads();
+        if (work) {
+#pragma unroll
+            for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
+                const int item = rnd * EW + tid;
+                const int hg = item / NG, hq = item - hg * NG;
+                if (item < ITEMS) {
+                    float o4[4];
+                    row_item<R, HA>(&l_tmp[buf][hg][4 * hq], tp, o4);
+                    const int cg = HA + 4 * hq, row = ii + hg, xo = g.X0 + cg;
+                    *reinterpret_cast<v4f*>(&ring[j & 1][hg][cg]) = v4f{o4[0], o4[1], o4[2], o4[3]};
+                    if (row >= g.i0 && row < g.i1 && xo >= g.keep_lo && xo < g.keep_hi)
+                        emit<PREV>(g, r_out, r_flags, o4, &l_prev[PREV ? buf : 0][PREV ? hg : 0][PREV ? cg : 0], flag_thr, row, xo);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+    }
+}
+
+template <int R, int HA, int HB, bool PREV>
+__device__ __forceinline__ void consumer(float* out_img, int* flags_img, const SaTapPairs& tp, float flag_thr, const Geo& g,
+                                         int r0, int warm, int tid, float (*l_tmp)[G][PITCH], float (*l_prev)[G][PITCH],
+                                         float (*ring)[G][PITCH])
+{
+    constexpr int OFF = HA + HB, NG = (EW - 2 * OFF) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
+    const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img);
+    v2f wp[NP];
+    float nx[G];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) wp[t] = v2f{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < G; ++q) nx[q] = 0.f;
+    int buf = 0;
+    for (int j = 0; j < g.n_iter; ++j, buf ^= 1) {
+        const int ii = r0 + G * j;
+        const bool work = j >= warm;         // the window holds produced rows only from here on
+#pragma unroll
+        for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
+        if (work) col_pass<R, PREV>(wp, tp, l_tmp[buf], l_prev[PREV ? buf : 0], tid);
+        __syncthreads();
+        // the rows the producer left in its previous iteration (slot (j-1)&1)
+#pragma unroll
+        for (int q = 0; q < G; ++q) nx[q] = ring[(j + 1) & 1][q][tid];
+        if (work) {
+#pragma unroll
+            for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
+                const int item = rnd * EW + tid;
+                const int hg = item / NG, hq = item - hg * NG;
+                const int cg = OFF + 4 * hq, row = ii + hg, xo = g.X0 + cg;
+                if (item < ITEMS && row < g.i1 && xo < g.keep_hi) {
+                    float o4[4];
+                    row_item<R, HB>(&l_tmp[buf][hg][cg - HB], tp, o4);
+                    emit<PREV>(g, r_out, r_flags, o4, &l_prev[PREV ? buf : 0][PREV ? hg : 0][PREV ? cg : 0], flag_thr, row, xo);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+    }
+}
+}  // namespace pairk
+
+// FA / FB: the producer's / the consumer's results carry contrast marks (at most one of them: the
+// buffer of centre samples exists once).
+template <int RA, int RB, bool FA, bool FB>
+__global__ void __launch_bounds__(1024)
+k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __restrict__ out_b, int w, int h,
+            long long s_in, long long s_a, long long s_b, SaTapPairs tp_a, SaTapPairs tp_b, int strip, int nbx, int nby,
+            int nblocks, int* __restrict__ flags, float flag_thr)
+{
+    using namespace pairk;
+    static_assert(!(FA && FB), "one buffer of centre samples");
+    constexpr int HA = (RA + 3) & ~3, HB = (RB + 3) & ~3, TWS = EW - 2 * (HA + HB);
+    constexpr bool PV = FA || FB;
+    __shared__ __attribute__((aligned(16))) float l_tmp[2][2][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float ring[2][G][PITCH];
+    __shared__ __attribute__((aligned(16))) float l_prev[PV ? 2 : 1][PV ? G : 1][PV ? PITCH : 4];
+    const int role = threadIdx.x >> 9, tid = threadIdx.x & (EW - 1);
+    const unsigned vid = xcd_remap(blockIdx.x, nblocks);
+    const int bx = vid % nbx, by = (vid / nbx) % nby;
+    const long long b = vid / (nbx * nby);
+    Geo g;
+    g.w = w; g.h = h;
+    g.X0 = bx * TWS - HA - HB;
+    g.keep_lo = bx * TWS; g.keep_hi = min(g.keep_lo + TWS, w);
+    g.i0 = by * strip; g.i1 = min(g.i0 + strip, h);
+    g.cells_w = (w + 63) >> 6;
+    const int warm = 2 + (RB + 3) / 4;
+    g.n_iter = warm + (g.i1 - g.i0 + G - 1) / G;
+    const int r0b = g.i0 - G * warm, r0a = r0b + RB + 16;
+    int* flags_img = flags ? flags + b * ((h + 7) >> 3) * (long long)g.cells_w : nullptr;
+    float (*prev_p)[G][PITCH] = reinterpret_cast<float (*)[G][PITCH]>(&l_prev[0][0][0]);   // (not touched without marks)
+    if (role == 0)
+        producer<RA, HA, HB, FA>(in + b * s_in, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a, tid, l_tmp[0], prev_p, ring);
+    else
+        consumer<RB, HA, HB, FB>(out_b + b * s_b, flags_img, tp_b, flag_thr, g, r0b, warm, tid, l_tmp[1], prev_p, ring);
+}
+
 // Any radius (taps in global memory); one thread per output sample.  Only used for
 // radii above SA_MAX_RADIUS_FAST, i.e. non-default parameters.
 __global__ void __launch_bounds__(256)
@@ -1796,6 +2003,46 @@ bool launch_blur_fused(hipStream_t st, const BlurArgs& a)
 #undef F
     }
     return true;
+}
+
+// Two blurs in one launch (k_blur_pair).  Returns false when this pair of radii / image shape has
+// no instantiation (`probe`: only that answer); the caller then issues the two blurs one after the other.
+bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe)
+{
+    if ((a.w & 3) || a.w < 900 || (a.flags && a.flag_on_a && a.flag_on_b)) return false;
+    // Tall strips: every strip repeats the consumer's warm-up (32 rows for radius 7).  Measured for 128
+    // 1080p images (octave 0 3840 x 2160): 1080 rows 2.72 ms, 544 rows 2.82, 272 rows 2.83, 136 rows
+    // 3.02.  Small batches would leave CUs without a block: they take the two-launch route.
+    // SIFT_AMD_PAIR_STRIP=<rows> forces the two-blur launch with that strip height (tests, A/B runs).
+    const char* fs = getenv("SIFT_AMD_PAIR_STRIP");
+    const int forced = fs ? atoi(fs) : 0;
+    int strip = forced > 0 ? ((forced + 7) & ~7) : 1080;
+    if (forced <= 0) {
+        auto blocks = [&](int st_) { return (long long)((a.w + 479) / 480) * ((a.h + st_ - 1) / st_) * a.batch; };
+        while (strip > 270 && blocks(strip) < 512) strip = ((strip / 2) + 7) & ~7;
+        if (blocks(strip) < 256) return false;
+    }
+    SaTapPairs ta, tb;
+    for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { ta.g[k] = v2f{a.taps_a.g[k], a.taps_a.g[k]}; tb.g[k] = v2f{a.taps_b.g[k], a.taps_b.g[k]}; }
+    const bool fa = a.flags && a.flag_on_a, fb = a.flags && a.flag_on_b;
+#define SA_PAIR(RA, RB, FA, FB)                                                                               \
+    do {                                                                                                      \
+        if (probe) return true;                                                                               \
+        constexpr int TWS = 512 - 2 * (((RA + 3) & ~3) + ((RB + 3) & ~3));                                    \
+        const int nbx = (a.w + TWS - 1) / TWS, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch; \
+        HIPK((k_blur_pair<RA, RB, FA, FB>), dim3(nblocks), dim3(1024), 0, st, a.in, a.out_a, a.out_b, a.w, a.h, a.s_in, \
+             a.s_a, a.s_b, ta, tb, strip, nbx, nby, nblocks, a.flags, a.flag_thr);                             \
+        return true;                                                                                          \
+    } while (0)
+    if (a.radius_a == 5 && a.radius_b == 7) {
+        if (fb) SA_PAIR(5, 7, false, true);
+        if (!fa) SA_PAIR(5, 7, false, false);
+    }
+    // (measured, 128 1080p images: radii 5 and 7 in one launch 2.73 ms against 1.64 + 1.74 ms apart;
+    // radii 10 and 13, which are bound by arithmetic and leave 456 columns per tile: 4.97 ms against
+    // 2.09 + 2.38 apart, so that pair stays two launches)
+#undef SA_PAIR
+    return false;
 }
 
 // Any-radius form, two launches.  pass 0: column pass (in -> tmp); pass 1: row pass (tmp -> out

@@ -27,6 +27,19 @@ struct BlurArgs {
     float flag_thr = 0.f;
 };
 
+// two successive blurs of one octave in one launch (in -> out_a -> out_b)
+struct BlurPairArgs {
+    const float* in;
+    float *out_a, *out_b;
+    long long s_in, s_a, s_b;
+    int w, h, batch;
+    int radius_a, radius_b;
+    SaTaps taps_a, taps_b;
+    int* flags = nullptr;        // contrast marks from the DoG of out_a (flag_on_a) or of out_b (flag_on_b)
+    bool flag_on_a = false, flag_on_b = false;
+    float flag_thr = 0.f;
+};
+bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe = false);
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
 bool launch_blur_fused(hipStream_t st, const BlurArgs& a);
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,

@@ -147,7 +147,7 @@ def test_wide_buffer_stores_keep_their_data_registers(tmp_path):
 def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
     asm = _disassembly(tmp_path)
     # every kernel whose float arithmetic decides discrete extrema or refined positions
-    families = ["k_blur_fused", "k_blur_v_any", "k_blur_h_any", "k_oversample", "k_subsample2", "k_sub",
+    families = ["k_blur_fused", "k_blur_pair", "k_blur_v_any", "k_blur_h_any", "k_oversample", "k_subsample2", "k_sub",
                 "k_gradient", "k_extrema", "k_refine"]
     pat = re.compile("|".join(families))
     current, fused, divs, seen = None, {}, {}, set()

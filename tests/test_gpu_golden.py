@@ -69,6 +69,8 @@ def test_hip_reproduces_golden(hip, name):
 # Diagnostic switches, read when a context is created.  Each selects another route through the
 # same arithmetic and must give the same bytes as the default route.
 SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
+            {"SIFT_AMD_PAIR": "0"},       # every blur a launch of its own (no two-blur launches)
+            {"SIFT_AMD_PAIR_STRIP": "64"},   # two-blur launches forced, in short strips
             {"SIFT_AMD_GRAPH": "0"},      # no hipGraph replay
             {"SIFT_AMD_DEBUG": "1"},      # generic descriptor instantiation
             {"SIFT_AMD_DEBUG": "2"},      # descriptor contributions listed per cell instead of per bin

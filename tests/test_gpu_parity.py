@@ -261,3 +261,26 @@ def test_unusual_sample_values(hip, name, value):
         got = np.stack([std["x"], std["y"], std["scale"], std["orientation"]], 1)
         assert same_bits(got, want["keys"]["flts"][:, :4])
         assert np.array_equal(descr, want["keys"]["descr"])
+
+
+def test_two_blur_launches_in_a_batch_equal_single_image_runs(hip):
+    """A batch large enough for the two-blur launch (images s and s+1 of an octave in one kernel,
+    chosen by the library from the number of blocks) gives the records of single-image runs, which
+    take one launch per blur."""
+    w, h, nb = 480, 270, 64
+    imgs = np.stack([synth.make(["white", "natural", "smooth"][b % 3], w, h, 4000 + b) for b in range(nb)])
+    with sift_amd.Context(w, h, max_batch=1) as one:
+        single = []
+        for b in (0, 1, 2, 3, 37, 63):
+            one.detect_host(imgs[b])
+            std, keys = one.keypoints(0)
+            single.append((b, std.tobytes(), keys.tobytes(),
+                           [one.scalespace(0, 0, o).tobytes() for o in range(one.n_oct)]))
+    with sift_amd.Context(w, h, max_batch=nb) as ctx:
+        ctx.detect_host(imgs)
+        for b, std_b, keys_b, gss in single:
+            std, keys = ctx.keypoints(b)
+            assert std.tobytes() == std_b and keys.tobytes() == keys_b, f"image {b}"
+            for o in range(ctx.n_oct):
+                assert ctx.scalespace(b, 0, o).tobytes() == gss[o], f"image {b} octave {o}"
+    assert len(single[0][1]) > 144 * 50
