@@ -10,6 +10,9 @@ OUT=$ROOT/gpurun_out/$TAG
 BATCH=128
 DOM_BLOCKS=$((8 * 17 * BATCH))
 DOM_THREADS=512
+# the radius-5/7 pair of octave 0 as one launch: 8 x 2 tiles of 480 x 1080 outputs per image, 1024 threads
+PAIR_BLOCKS=$((8 * 2 * BATCH))
+PAIR_THREADS=1024
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- \
@@ -17,10 +20,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 cd $ROOT
 python3 tools/prof_summary.py $OUT/stats > $OUT/kernel_stats.md
 python3 tools/trace_by_grid.py $OUT/stats "" 40 > $OUT/by_grid.txt
-python3 tools/dominant_from_trace.py $OUT/stats $DOM_BLOCKS 50 > $OUT/dominant_kernel_rocprof.txt
+python3 tools/dominant_from_trace.py $OUT/stats $DOM_BLOCKS 40 $PAIR_BLOCKS > $OUT/dominant_kernel_rocprof.txt
 bash tools/pmc_passes.sh $TAG/pmc > $OUT/pmc.log 2>&1
-python3 tools/pmc_summary.py $OUT/pmc k_blur_fused > $OUT/pmc_blur.txt
-python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)) $BATCH $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
+python3 tools/pmc_summary.py $OUT/pmc k_blur_ > $OUT/pmc_blur.txt
+python3 tools/make_traffic.py $OUT/pmc $((DOM_BLOCKS * DOM_THREADS)),$((PAIR_BLOCKS * PAIR_THREADS)) $BATCH $OUT/traffic.json > /dev/null 2> $OUT/traffic.err || true
 [ -s $OUT/traffic.json ] && cp $OUT/traffic.json $ROOT/profiles/traffic.json   # the bench line quotes it
 bash tools/pmc_one.sh $TAG/grbm GRBM_GUI_ACTIVE > $OUT/grbm.log 2>&1
 python3 tools/clock_from_pmc.py $OUT/grbm > $OUT/clock_per_kernel.md
