@@ -582,9 +582,47 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
         const long long sg = ns * np, sd = (ns - 1) * np;
         float* g = c->d_gss[o];
         float* d = c->d_dog[o];
+        // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
+        auto marked = [&](int sc) { return mark && sc - 1 >= 1 && sc - 1 <= ns - 3; };
+        auto emits_next_octave = [&](int sc) { return sc == ns - 3 && o + 1 < L.n_oct; };
+        // Images sa and sa+1 in one launch where an instantiation exists (image sa is then written but
+        // not read back); sa = 0: the seed image, whose source is the oversampled input.  Not for
+        // contexts that store DoG images.
+        auto try_pair = [&](int sa) -> bool {
+            if (!c->use_pairs || d || sa + 1 >= ns || emits_next_octave(sa)) return false;
+            sa::BlurPairArgs pa;
+            const BlurSpec& ba = sa == 0 ? c->seed : c->step[o][sa];
+            const BlurSpec& bb = c->step[o][sa + 1];
+            if (sa == 0) {
+                if (o != 0 || !(L.delta[0] < 1.f)) return false;
+                pa.in = d_images; pa.s_in = (long long)c->im_w * c->im_h;
+                pa.ovs_w = c->im_w; pa.ovs_h = c->im_h; pa.ovs_delta = L.delta[0];
+            } else {
+                pa.in = g + (sa - 1) * np; pa.s_in = sg;
+            }
+            pa.out_a = g + sa * np; pa.out_b = g + (sa + 1) * np;
+            pa.s_a = pa.s_b = sg;
+            pa.w = L.w[o]; pa.h = L.h[o]; pa.batch = n;
+            pa.radius_a = ba.radius; pa.radius_b = bb.radius;
+            pa.taps_a = ba.taps; pa.taps_b = bb.taps;
+            pa.flag_on_a = marked(sa); pa.flag_on_b = marked(sa + 1);
+            pa.flags = (pa.flag_on_a || pa.flag_on_b) ? c->d_cells[o] : nullptr;
+            pa.flag_thr = c->sc.thr_pre;
+            if (emits_next_octave(sa + 1)) {
+                pa.sub = c->d_gss[o + 1];
+                pa.s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
+            }
+            if (!sa::launch_blur_pair(st, pa, true)) return false;
+            ProfScope ps(c, st, SIFT_AMD_K_BLUR_FUSED, o, sa + 1);     // (timed under the second image of the pair)
+            sa::launch_blur_pair(st, pa);
+            return true;
+        };
+        int s_first = 1;
         if (o == 0) {
             const bool fuse_ovs = c->seed.radius >= 1 && c->seed.radius <= SA_MAX_RADIUS_FAST;
-            if (L.delta[0] < 1.f && fuse_ovs) {
+            if (L.delta[0] < 1.f && fuse_ovs && try_pair(0)) {
+                s_first = 2;
+            } else if (L.delta[0] < 1.f && fuse_ovs) {
                 // oversampling evaluated inside the seed blur's loads: no oversampled image in memory
                 run_blur(c, st, 0, 0, c->seed, d_images, (long long)c->im_w * c->im_h, g, sg, nullptr, 0, nullptr, 0, n,
                          c->im_w, c->im_h, L.delta[0]);
@@ -599,36 +637,13 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
         }
         // octaves o > 0 start from the even samples of image n_spo of the octave below
         // (lib_sift_anatomy.c:142-149), written by that image's blur
-        for (int s = 1; s < ns; s++) {
+        for (int s = s_first; s < ns; s++) {
+            if (try_pair(s)) { ++s; continue; }
             float* sub = nullptr;
             long long s_sub = 0;
-            if (s == ns - 3 && o + 1 < L.n_oct) {
+            if (emits_next_octave(s)) {
                 sub = c->d_gss[o + 1];
                 s_sub = (long long)ns * L.w[o + 1] * L.h[o + 1];
-            }
-            // DoG image s-1 is a centre scale of the extrema scan for s-1 in 1..ns-3
-            auto marked = [&](int sc) { return mark && sc - 1 >= 1 && sc - 1 <= ns - 3; };
-            auto emits_next_octave = [&](int sc) { return sc == ns - 3 && o + 1 < L.n_oct; };
-            // images s and s+1 in one launch where an instantiation exists (image s is then
-            // written but not read back); not for contexts that store DoG images
-            if (c->use_pairs && !d && s + 1 < ns && !emits_next_octave(s) && !emits_next_octave(s + 1) &&
-                !(marked(s) && marked(s + 1))) {
-                sa::BlurPairArgs pa;
-                pa.in = g + (s - 1) * np; pa.out_a = g + s * np; pa.out_b = g + (s + 1) * np;
-                pa.s_in = pa.s_a = pa.s_b = sg;
-                pa.w = L.w[o]; pa.h = L.h[o]; pa.batch = n;
-                pa.radius_a = c->step[o][s].radius; pa.radius_b = c->step[o][s + 1].radius;
-                pa.taps_a = c->step[o][s].taps; pa.taps_b = c->step[o][s + 1].taps;
-                pa.flag_on_a = marked(s); pa.flag_on_b = marked(s + 1);
-                pa.flags = (pa.flag_on_a || pa.flag_on_b) ? c->d_cells[o] : nullptr;
-                pa.flag_thr = c->sc.thr_pre;
-                if (sa::launch_blur_pair(st, pa, true)) {
-                    // (timed under the second image of the pair)
-                    ProfScope ps(c, st, SIFT_AMD_K_BLUR_FUSED, o, s + 1);
-                    sa::launch_blur_pair(st, pa);
-                    ++s;
-                    continue;
-                }
             }
             int* cells = nullptr;
             if (marked(s)) {

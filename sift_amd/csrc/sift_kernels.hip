@@ -542,18 +542,19 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 // ------------------------------------------------- two blurs in one launch --
 // Two successive blurs of an octave (image s-1 -> s -> s+1) in one launch, so that image s is
 // written but never read back: 12 instead of 16 bytes per pixel.  A block of 1024 threads has two
-// roles of 8 waves each.  The producer is the fused blur above (source rows from global memory,
-// column pass in registers, row pass through LDS) and also leaves its output rows, 8 per iteration,
-// in an LDS ring; the consumer runs the same two passes with radius RB on the rows it takes from the
-// ring.  Both roles share one barrier per iteration: the producer fills ring slot j&1 behind barrier
-// j, the consumer reads it behind barrier j+1 and uses it in iteration j+2, so the consumer trails by
-// 16 + RB rows and warms up for MB = 2 + ceil(RB/4) iterations before its window is complete.  Rows
-// and columns outside the image are produced at their mirrored positions, which gives the bits of the
-// mirrored result (the taps are symmetric and the pair sums commute).  A tile is 512 columns wide:
-// the producer's results are valid on 512 - 2 HA of them, the consumer's on 512 - 2 (HA + HB), the
-// columns a block stores (HA, HB: the radii rounded up to a multiple of 4).
+// roles of 8 waves each.  The producer is the fused blur above (source rows from global memory, or
+// the bilinearly oversampled input for the seed image; column pass in registers, row pass through
+// LDS) and also leaves its output rows, 8 per iteration, in an LDS ring; the consumer runs the same
+// two passes with radius RB on the rows it takes from the ring.  Both roles share one barrier per
+// iteration: the producer fills ring slot j&1 behind barrier j, the consumer reads it behind barrier
+// j+1 and uses it in iteration j+2, so the consumer trails by 16 + RB rows and warms up for
+// 2 + ceil(RB/4) iterations before its window is complete.  Rows and columns outside the image are
+// produced at their mirrored positions, which gives the bits of the mirrored result (the taps are
+// symmetric and the pair sums commute).  A tile is 512 columns wide: the producer's results are
+// valid on 512 - 2 HA of them, the consumer's on 512 - 2 (HA + HB), the columns a block stores
+// (HA, HB: the radii rounded up to a multiple of 4).
 namespace pairk {
-constexpr int G = 8, EW = 512, PITCH = EW + 32;
+constexpr int G = 8, EW = 512;
 struct Geo {
     int w, h;
     int X0;                 // global column of tile-local column 0
@@ -583,9 +584,10 @@ __device__ __forceinline__ void row_item(const float* lrow, const SaTapPairs& tp
     o4[0] = o01.x; o4[1] = o01.y; o4[2] = o23.x; o4[3] = o23.y;
 }
 
-// column pass of one iteration: 8 outputs of column tid from the register window
-template <int R, bool PREV>
-__device__ __forceinline__ void col_pass(const v2f* wp, const SaTapPairs& tp, float (*tmp)[PITCH], float (*prev)[PITCH], int tid)
+// column pass of one iteration: 8 outputs of column tid from the register window; tmp / prev point
+// at the iteration's 8 x PITCH buffers
+template <int R, int PITCH, bool PREV>
+__device__ __forceinline__ void col_pass(const v2f* wp, const SaTapPairs& tp, float* tmp, float* prev, int tid)
 {
 #pragma unroll
     for (int g = 0; g < G; g += 2) {
@@ -593,16 +595,18 @@ __device__ __forceinline__ void col_pass(const v2f* wp, const SaTapPairs& tp, fl
         v2f s = ctr * tp.g[0];
 #pragma unroll
         for (int k = 1; k <= R; ++k) s = s + tp.g[k] * win_pair_sum(wp, g + R - k, g + R + k);
-        tmp[g][tid] = s.x;
-        tmp[g + 1][tid] = s.y;
-        if (PREV) { prev[g][tid] = ctr.x; prev[g + 1][tid] = ctr.y; }
+        tmp[g * PITCH + tid] = s.x;
+        tmp[(g + 1) * PITCH + tid] = s.y;
+        if (PREV) { prev[g * PITCH + tid] = ctr.x; prev[(g + 1) * PITCH + tid] = ctr.y; }
     }
 }
 
-// stores 4 results (and, with PREV, the contrast mark of their cell)
-template <bool PREV>
+// stores 4 results; with PREV the contrast mark of their cell; with SUB the even samples of even
+// rows into the next octave's first image (lib_discrete.c:180-191)
+template <bool PREV, bool SUB>
 __device__ __forceinline__ void emit(const Geo& g, __amdgpu_buffer_rsrc_t r_out, __amdgpu_buffer_rsrc_t r_flags,
-                                     const float (&o4)[4], const float* prev4, float flag_thr, int row, int xo)
+                                     __amdgpu_buffer_rsrc_t r_sub, const float (&o4)[4], const float* prev4,
+                                     float flag_thr, int row, int xo)
 {
     buf_st4(r_out, (unsigned)(row * g.w + xo) * 4u, 0u, v4f{o4[0], o4[1], o4[2], o4[3]});
     if (PREV) {
@@ -612,19 +616,82 @@ __device__ __forceinline__ void emit(const Geo& g, __amdgpu_buffer_rsrc_t r_out,
         if (m > flag_thr)
             __builtin_amdgcn_raw_buffer_store_b32(1u, r_flags, (unsigned)((row >> 3) * g.cells_w + (xo >> 6)) * 4u, 0u, 0);
     }
+    if (SUB && !(row & 1) && (row >> 1) < (g.h >> 1))
+        buf_st2(r_sub, (unsigned)((row >> 1) * (g.w >> 1) + (xo >> 1)) * 4u, 0u, v2f{o4[0], o4[2]});
 }
 
-template <int R, int HA, int HB, bool PREV>
-__device__ __forceinline__ void producer(const float* in_img, float* out_img, int* flags_img, const SaTapPairs& tp, float flag_thr,
-                                         const Geo& g, int r0, int tid, float (*l_tmp)[G][PITCH], float (*l_prev)[G][PITCH],
-                                         float (*ring)[G][PITCH])
+template <int R, int HA, int HB, int PITCH, bool PREV, bool OVS>
+__device__ __forceinline__ void producer(const float* in_img, int wi, int hi, float delta, float* out_img, int* flags_img,
+                                         const SaTapPairs& tp, float flag_thr, const Geo& g, int r0, int tid,
+                                         float* l_tmp, float* l_prev, float* ring)
 {
     constexpr int NG = (EW - 2 * HA) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
     const __amdgpu_buffer_rsrc_t src = buf_rsrc(in_img), r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img);
-    const unsigned ucol = (unsigned)mirror_idx(g.X0 + tid, g.w) * 4u;
-    auto load = [&](int i) -> float { return buf_ld(src, ucol, (unsigned)(mirror_idx(i, g.h) * g.w) * 4u); };
+    const int col = mirror_idx(g.X0 + tid, g.w);
+    const unsigned ucol = (unsigned)col * 4u;
+    OvsCol oc;
+    if (OVS) {
+        const float y = col * delta;
+        oc.jm = (int)y; oc.jp = oc.jm + 1;
+        if (oc.jp >= wi) oc.jp = 2 * wi - 1 - oc.jp;
+        if (oc.jm >= wi) oc.jm = 2 * wi - 1 - oc.jm;
+        oc.fy = y - floorf(y);
+    }
+    auto load = [&](int i) -> float {
+        const int r = mirror_idx(i, g.h);
+        if (OVS) return ovs_sample(src, wi, hi, delta, r, oc);
+        return buf_ld(src, ucol, (unsigned)(r * g.w) * 4u);
+    };
     v2f wp[NP];
     float nx[G];
+    // Prefetch of the next 8 rows.  With the oversampling at step 1/2, rows 2m and 2m+1 interpolate
+    // the same two input rows: their horizontally interpolated rows are loaded once (raw samples
+    // issued here, interpolation at the top of the next iteration); rows that need mirroring take
+    // the per-sample path (same expressions as k_blur_fused).
+    const bool half_step = OVS && delta == 0.5f;
+    float raw[OVS ? 2 * (G / 2 + 2) : 1];
+    bool raw_pending = false, raw_odd = false;
+    auto issue_rows = [&](int ifirst) {
+        if (OVS && half_step && ifirst >= 0 && ifirst + G - 1 < g.h && ((ifirst + G - 1) >> 1) + 1 < hi) {
+            const int m = ifirst >> 1;
+            raw_odd = ifirst & 1;
+#pragma unroll
+            for (int t = 0; t < G / 2 + 2; ++t) {
+                const unsigned rp = (unsigned)(min(m + t, hi - 1) * wi) * 4u;
+                raw[OVS ? 2 * t : 0] = buf_ld(src, oc.jp * 4u, rp);
+                raw[OVS ? 2 * t + 1 : 0] = buf_ld(src, oc.jm * 4u, rp);
+            }
+            raw_pending = true;
+        } else {
+            raw_pending = false;
+#pragma unroll
+            for (int q = 0; q < G; ++q) nx[q] = load(ifirst + q);
+        }
+    };
+    auto finish_rows = [&]() {
+        if (!OVS || !raw_pending) return;
+        float H[G / 2 + 2];
+#pragma unroll
+        for (int t = 0; t < G / 2 + 2; ++t)
+            H[t] = __fadd_rn(__fmul_rn(oc.fy, raw[OVS ? 2 * t : 0]), __fmul_rn(1 - oc.fy, raw[OVS ? 2 * t + 1 : 0]));
+        // row ifirst + q: input rows (ifirst + q) / 2 and the next one, weight 1/2 on odd rows
+        if (raw_odd) {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int t = (q + 1) >> 1;
+                const float fx = ((q + 1) & 1) ? 0.5f : 0.f;
+                nx[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int t = q >> 1;
+                const float fx = (q & 1) ? 0.5f : 0.f;
+                nx[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+            }
+        }
+        raw_pending = false;
+    };
     {
         float pro[2 * R];
 #pragma unroll
@@ -632,33 +699,33 @@ __device__ __forceinline__ void producer(const float* in_img, float* out_img, in
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = v2f{pro[2 * t], pro[2 * t + 1]};
     }
-#pragma unroll
-    for (int q = 0; q < G; ++q) nx[q] = load(r0 + R + q);
+    issue_rows(r0 + R);
     int buf = 0;
     for (int j = 0; j < g.n_iter; ++j, buf ^= 1) {
         const int ii = r0 + G * j;
         // the rows of the last two iterations would reach the consumer after its last iteration
         const bool work = j + 2 < g.n_iter;
+        finish_rows();
 #pragma unroll
         for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
-        if (j + 3 < g.n_iter) {
-#pragma unroll
-            for (int q = 0; q < G; ++q) nx[q] = load(ii + G + R + q);
-        }
-        if (work) col_pass<R, PREV>(wp, tp, l_tmp[buf], l_prev[PREV ? buf : 0], tid);
+        if (j + 3 < g.n_iter) issue_rows(ii + G + R);
+        float* tmp = l_tmp + buf * G * PITCH;
+        float* prev = l_prev + (PREV ? buf * G * PITCH : 0);
+        if (work) col_pass<R, PITCH, PREV>(wp, tp, tmp, prev, tid);
         __syncthreads();
         if (work) {
+            float* slot = ring + (j & 1) * G * PITCH;
 #pragma unroll
             for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
                 const int item = rnd * EW + tid;
                 const int hg = item / NG, hq = item - hg * NG;
                 if (item < ITEMS) {
                     float o4[4];
-                    row_item<R, HA>(&l_tmp[buf][hg][4 * hq], tp, o4);
+                    row_item<R, HA>(tmp + hg * PITCH + 4 * hq, tp, o4);
                     const int cg = HA + 4 * hq, row = ii + hg, xo = g.X0 + cg;
-                    *reinterpret_cast<v4f*>(&ring[j & 1][hg][cg]) = v4f{o4[0], o4[1], o4[2], o4[3]};
+                    *reinterpret_cast<v4f*>(slot + hg * PITCH + cg) = v4f{o4[0], o4[1], o4[2], o4[3]};
                     if (row >= g.i0 && row < g.i1 && xo >= g.keep_lo && xo < g.keep_hi)
-                        emit<PREV>(g, r_out, r_flags, o4, &l_prev[PREV ? buf : 0][PREV ? hg : 0][PREV ? cg : 0], flag_thr, row, xo);
+                        emit<PREV, false>(g, r_out, r_flags, r_out, o4, prev + (PREV ? hg * PITCH + cg : 0), flag_thr, row, xo);
                 }
             }
         }
@@ -667,13 +734,12 @@ __device__ __forceinline__ void producer(const float* in_img, float* out_img, in
     }
 }
 
-template <int R, int HA, int HB, bool PREV>
-__device__ __forceinline__ void consumer(float* out_img, int* flags_img, const SaTapPairs& tp, float flag_thr, const Geo& g,
-                                         int r0, int warm, int tid, float (*l_tmp)[G][PITCH], float (*l_prev)[G][PITCH],
-                                         float (*ring)[G][PITCH])
+template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB>
+__device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* sub_img, const SaTapPairs& tp, float flag_thr,
+                                         const Geo& g, int r0, int warm, int tid, float* l_tmp, float* l_prev, float* ring)
 {
     constexpr int OFF = HA + HB, NG = (EW - 2 * OFF) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
-    const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img);
+    const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img), r_sub = buf_rsrc(sub_img);
     v2f wp[NP];
     float nx[G];
 #pragma unroll
@@ -686,11 +752,14 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, const S
         const bool work = j >= warm;         // the window holds produced rows only from here on
 #pragma unroll
         for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
-        if (work) col_pass<R, PREV>(wp, tp, l_tmp[buf], l_prev[PREV ? buf : 0], tid);
+        float* tmp = l_tmp + buf * G * PITCH;
+        float* prev = l_prev + (PREV ? buf * G * PITCH : 0);
+        if (work) col_pass<R, PITCH, PREV>(wp, tp, tmp, prev, tid);
         __syncthreads();
         // the rows the producer left in its previous iteration (slot (j-1)&1)
+        const float* slot = ring + ((j + 1) & 1) * G * PITCH;
 #pragma unroll
-        for (int q = 0; q < G; ++q) nx[q] = ring[(j + 1) & 1][q][tid];
+        for (int q = 0; q < G; ++q) nx[q] = slot[q * PITCH + tid];
         if (work) {
 #pragma unroll
             for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
@@ -699,8 +768,8 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, const S
                 const int cg = OFF + 4 * hq, row = ii + hg, xo = g.X0 + cg;
                 if (item < ITEMS && row < g.i1 && xo < g.keep_hi) {
                     float o4[4];
-                    row_item<R, HB>(&l_tmp[buf][hg][cg - HB], tp, o4);
-                    emit<PREV>(g, r_out, r_flags, o4, &l_prev[PREV ? buf : 0][PREV ? hg : 0][PREV ? cg : 0], flag_thr, row, xo);
+                    row_item<R, HB>(tmp + hg * PITCH + cg - HB, tp, o4);
+                    emit<PREV, SUB>(g, r_out, r_flags, r_sub, o4, prev + (PREV ? hg * PITCH + cg : 0), flag_thr, row, xo);
                 }
             }
         }
@@ -710,21 +779,23 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, const S
 }
 }  // namespace pairk
 
-// FA / FB: the producer's / the consumer's results carry contrast marks (at most one of them: the
-// buffer of centre samples exists once).
-template <int RA, int RB, bool FA, bool FB>
+// FA / FB: the producer's / the consumer's results carry contrast marks; OVS: the producer's source
+// is the bilinear oversampling of `in` (wi x hi, step delta) evaluated in its loads; SUB: the
+// consumer's image also yields the next octave's first image.  With marks on both images all LDS
+// rows are 512 floats (exactly the CU's 160 KB), otherwise 544 (conflict-free row-pass reads).
+template <int RA, int RB, bool FA, bool FB, bool OVS, bool SUB>
 __global__ void __launch_bounds__(1024)
-k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __restrict__ out_b, int w, int h,
-            long long s_in, long long s_a, long long s_b, SaTapPairs tp_a, SaTapPairs tp_b, int strip, int nbx, int nby,
-            int nblocks, int* __restrict__ flags, float flag_thr)
+k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __restrict__ out_b, float* __restrict__ sub,
+            int w, int h, long long s_in, long long s_a, long long s_b, long long s_sub, SaTapPairs tp_a, SaTapPairs tp_b,
+            int strip, int nbx, int nby, int nblocks, int wi, int hi, float delta, int* __restrict__ flags, float flag_thr)
 {
     using namespace pairk;
-    static_assert(!(FA && FB), "one buffer of centre samples");
     constexpr int HA = (RA + 3) & ~3, HB = (RB + 3) & ~3, TWS = EW - 2 * (HA + HB);
-    constexpr bool PV = FA || FB;
-    __shared__ __attribute__((aligned(16))) float l_tmp[2][2][G][PITCH];
-    __shared__ __attribute__((aligned(16))) float ring[2][G][PITCH];
-    __shared__ __attribute__((aligned(16))) float l_prev[PV ? 2 : 1][PV ? G : 1][PV ? PITCH : 4];
+    constexpr int PITCH = (FA && FB) ? EW : EW + 32;
+    __shared__ __attribute__((aligned(16))) float l_tmp[2][2 * G * PITCH];
+    __shared__ __attribute__((aligned(16))) float ring[2 * G * PITCH];
+    __shared__ __attribute__((aligned(16))) float l_prev_a[FA ? 2 * G * PITCH : 4];
+    __shared__ __attribute__((aligned(16))) float l_prev_b[FB ? 2 * G * PITCH : 4];
     const int role = threadIdx.x >> 9, tid = threadIdx.x & (EW - 1);
     const unsigned vid = xcd_remap(blockIdx.x, nblocks);
     const int bx = vid % nbx, by = (vid / nbx) % nby;
@@ -739,11 +810,12 @@ k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __re
     g.n_iter = warm + (g.i1 - g.i0 + G - 1) / G;
     const int r0b = g.i0 - G * warm, r0a = r0b + RB + 16;
     int* flags_img = flags ? flags + b * ((h + 7) >> 3) * (long long)g.cells_w : nullptr;
-    float (*prev_p)[G][PITCH] = reinterpret_cast<float (*)[G][PITCH]>(&l_prev[0][0][0]);   // (not touched without marks)
     if (role == 0)
-        producer<RA, HA, HB, FA>(in + b * s_in, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a, tid, l_tmp[0], prev_p, ring);
+        producer<RA, HA, HB, PITCH, FA, OVS>(in + b * s_in, wi, hi, delta, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a,
+                                             tid, l_tmp[0], l_prev_a, ring);
     else
-        consumer<RB, HA, HB, FB>(out_b + b * s_b, flags_img, tp_b, flag_thr, g, r0b, warm, tid, l_tmp[1], prev_p, ring);
+        consumer<RB, HA, HB, PITCH, FB, SUB>(out_b + b * s_b, flags_img, SUB ? sub + b * s_sub : nullptr, tp_b, flag_thr, g, r0b,
+                                             warm, tid, l_tmp[1], l_prev_b, ring);
 }
 
 // Any radius (taps in global memory); one thread per output sample.  Only used for
@@ -2007,9 +2079,15 @@ bool launch_blur_fused(hipStream_t st, const BlurArgs& a)
 
 // Two blurs in one launch (k_blur_pair).  Returns false when this pair of radii / image shape has
 // no instantiation (`probe`: only that answer); the caller then issues the two blurs one after the other.
+// Instantiations: the pairs of the default parameters that arithmetic does not bound and whose tiles
+// keep 480 of 512 columns (seed 5 + 5, 5 + 7, 7 + 8).  Measured, 128 1080p images: radii 5 and 7 in
+// one launch 2.73 ms against 1.64 + 1.74 ms apart; radii 10 and 13 (456 columns per tile) 4.97 ms
+// against 2.09 + 2.38 apart, so that pair stays two launches.
 bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe)
 {
-    if ((a.w & 3) || a.w < 900 || (a.flags && a.flag_on_a && a.flag_on_b)) return false;
+    if ((a.w & 3) || a.w < 900) return false;
+    const bool ovs = a.ovs_w > 0;
+    if (ovs && (a.flag_on_a || a.flag_on_b || a.sub)) return false;
     // Tall strips: every strip repeats the consumer's warm-up (32 rows for radius 7).  Measured for 128
     // 1080p images (octave 0 3840 x 2160): 1080 rows 2.72 ms, 544 rows 2.82, 272 rows 2.83, 136 rows
     // 3.02.  Small batches would leave CUs without a block: they take the two-launch route.
@@ -2024,23 +2102,31 @@ bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe)
     }
     SaTapPairs ta, tb;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { ta.g[k] = v2f{a.taps_a.g[k], a.taps_a.g[k]}; tb.g[k] = v2f{a.taps_b.g[k], a.taps_b.g[k]}; }
-    const bool fa = a.flags && a.flag_on_a, fb = a.flags && a.flag_on_b;
-#define SA_PAIR(RA, RB, FA, FB)                                                                               \
+    const bool fa = a.flags && a.flag_on_a, fb = a.flags && a.flag_on_b, sub = a.sub != nullptr;
+#define SA_PAIR(RA, RB, FA, FB, OVS, SUB)                                                                     \
     do {                                                                                                      \
         if (probe) return true;                                                                               \
         constexpr int TWS = 512 - 2 * (((RA + 3) & ~3) + ((RB + 3) & ~3));                                    \
         const int nbx = (a.w + TWS - 1) / TWS, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch; \
-        HIPK((k_blur_pair<RA, RB, FA, FB>), dim3(nblocks), dim3(1024), 0, st, a.in, a.out_a, a.out_b, a.w, a.h, a.s_in, \
-             a.s_a, a.s_b, ta, tb, strip, nbx, nby, nblocks, a.flags, a.flag_thr);                             \
+        HIPK((k_blur_pair<RA, RB, FA, FB, OVS, SUB>), dim3(nblocks), dim3(1024), 0, st, a.in, a.out_a, a.out_b, a.sub, \
+             a.w, a.h, a.s_in, a.s_a, a.s_b, a.s_sub, ta, tb, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h,      \
+             a.ovs_delta, a.flags, a.flag_thr);                                                               \
         return true;                                                                                          \
     } while (0)
-    if (a.radius_a == 5 && a.radius_b == 7) {
-        if (fb) SA_PAIR(5, 7, false, true);
-        if (!fa) SA_PAIR(5, 7, false, false);
+    if (ovs) {
+        if (a.radius_a == 5 && a.radius_b == 5) SA_PAIR(5, 5, false, false, true, false);
+        return false;
     }
-    // (measured, 128 1080p images: radii 5 and 7 in one launch 2.73 ms against 1.64 + 1.74 ms apart;
-    // radii 10 and 13, which are bound by arithmetic and leave 456 columns per tile: 4.97 ms against
-    // 2.09 + 2.38 apart, so that pair stays two launches)
+    if (a.radius_a == 5 && a.radius_b == 7 && !fa && !sub) {
+        if (fb) SA_PAIR(5, 7, false, true, false, false);
+        SA_PAIR(5, 7, false, false, false, false);
+    }
+    if (a.radius_a == 7 && a.radius_b == 8 && fa == fb) {
+        if (fa && sub) SA_PAIR(7, 8, true, true, false, true);
+        if (fa) SA_PAIR(7, 8, true, true, false, false);
+        if (sub) SA_PAIR(7, 8, false, false, false, true);
+        SA_PAIR(7, 8, false, false, false, false);
+    }
 #undef SA_PAIR
     return false;
 }

@@ -35,9 +35,15 @@ struct BlurPairArgs {
     int w, h, batch;
     int radius_a, radius_b;
     SaTaps taps_a, taps_b;
-    int* flags = nullptr;        // contrast marks from the DoG of out_a (flag_on_a) or of out_b (flag_on_b)
+    int* flags = nullptr;        // contrast marks from the DoG of out_a (flag_on_a) and/or of out_b (flag_on_b)
     bool flag_on_a = false, flag_on_b = false;
     float flag_thr = 0.f;
+    float* sub = nullptr;        // optional: even samples of out_b (the next octave's first image)
+    long long s_sub = 0;
+    // if ovs_w > 0, `in` is the ovs_w x ovs_h input image and the first blur's source is its bilinear
+    // oversampling at step ovs_delta (w x h = oversampled size)
+    int ovs_w = 0, ovs_h = 0;
+    float ovs_delta = 0.f;
 };
 bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe = false);
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
