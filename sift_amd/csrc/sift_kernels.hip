@@ -443,18 +443,29 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nx[2 * q]; wp[R + q].y = nx[2 * q + 1]; }
         if (ii + G < i1) issue_rows(ii + G + R);
         if (NBUF == 1) __syncthreads();
+        // two output pairs at a time: the two accumulation chains are independent, so a wave has a
+        // second instruction to issue while the first one's result is on its way
 #pragma unroll
-        for (int g = 0; g < G; g += 2) {
-            const v2f ctr = win_pair(wp, g + R);
-            v2f s = ctr * tp.g[0];
+        for (int g = 0; g < G; g += 4) {
+            const v2f ctr0 = win_pair(wp, g + R), ctr1 = win_pair(wp, g + 2 + R);
+            v2f s0 = ctr0 * tp.g[0], s1 = ctr1 * tp.g[0];
 #pragma unroll
-            for (int k = 1; k <= R; ++k)
-                s = s + tp.g[k] * win_pair_sum(wp, g + R - k, g + R + k);
-            l_tmp[buf][g][tid] = s.x;
-            l_tmp[buf][g + 1][tid] = s.y;
+            for (int k = 1; k <= R; ++k) {
+                const v2f a0 = win_pair_sum(wp, g + R - k, g + R + k);
+                const v2f a1 = win_pair_sum(wp, g + 2 + R - k, g + 2 + R + k);
+                const v2f m0 = tp.g[k] * a0, m1 = tp.g[k] * a1;
+                s0 = s0 + m0;
+                s1 = s1 + m1;
+            }
+            l_tmp[buf][g][tid] = s0.x;
+            l_tmp[buf][g + 1][tid] = s0.y;
+            l_tmp[buf][g + 2][tid] = s1.x;
+            l_tmp[buf][g + 3][tid] = s1.y;
             if (PREV) {                  // unfiltered centre samples, for the DoG epilogue
-                l_prev[buf][g][tid] = ctr.x;
-                l_prev[buf][g + 1][tid] = ctr.y;
+                l_prev[buf][g][tid] = ctr0.x;
+                l_prev[buf][g + 1][tid] = ctr0.y;
+                l_prev[buf][g + 2][tid] = ctr1.x;
+                l_prev[buf][g + 3][tid] = ctr1.y;
             }
         }
         __syncthreads();
