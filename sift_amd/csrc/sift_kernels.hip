@@ -265,6 +265,8 @@ __device__ __forceinline__ v2f win_pair(const v2f* p, int a)
 }
 // Taps duplicated into pairs: packed multiplies take them straight from SGPR pairs.
 struct SaTapPairs { v2f g[SA_MAX_RADIUS_FAST + 1]; };
+struct SaTrue { static constexpr bool value = true; };
+struct SaFalse { static constexpr bool value = false; };
 
 #ifdef SA_BLUR_CLOCK
 // Diagnostic build only: shader-clock ticks and 100 MHz real-time ticks spent inside the blur
@@ -436,12 +438,22 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     };
     issue_rows(i0 + R);
 
-    int buf = 0;
-    for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
-        finish_rows();
+    // One iteration: 8 rows of the strip starting at row ii.  nxr holds their newest source rows,
+    // prefetch() starts the loads of a later iteration once nxr has been taken into the window.
+    auto iteration = [&](int ii, int buf, float (&nxr)[G], auto&& prefetch, auto pinned) {
+        if constexpr (decltype(pinned)::value) {
+            // asm moves: the copies out of the load registers stay here, where only these rows' loads
+            // have to be complete, instead of becoming register copies at the loop's back edge
 #pragma unroll
-        for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nx[2 * q]; wp[R + q].y = nx[2 * q + 1]; }
-        if (ii + G < i1) issue_rows(ii + G + R);
+            for (int q = 0; q < G / 2; ++q) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wp[R + q].x) : "v"(nxr[2 * q]));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wp[R + q].y) : "v"(nxr[2 * q + 1]));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nxr[2 * q]; wp[R + q].y = nxr[2 * q + 1]; }
+        }
+        prefetch();
         if (NBUF == 1) __syncthreads();
         // two output pairs at a time: the two accumulation chains are independent, so a wave has a
         // second instruction to issue while the first one's result is on its way
@@ -541,6 +553,34 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         }
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+    };
+    if (!OVS && EW == 512 && strip >= 8 * G) {
+        // Source rows are fetched two iterations ahead, into two register sets used in turn.  When an
+        // iteration waits for its rows, the eight loads of the following iteration are always younger
+        // than them: the wait (vmcnt counts loads and stores in issue order) then never extends to
+        // the stores the wave has just issued.  With a distance of one iteration every wave waited
+        // for the write acknowledgements of its last stores once per iteration.  Loads past the
+        // strip are issued with an out-of-range lane offset (dropped by the range check), so that
+        // the number of loads per iteration does not depend on the path taken.
+        float nxb[G];
+        auto issue_into = [&](float (&dst)[G], int ifirst, bool live) {
+            const unsigned lane = live ? ucol : 0x80000000u;
+#pragma unroll
+            for (int g = 0; g < G; ++g) dst[g] = buf_ld(src, lane, (unsigned)(mirror_idx(ifirst + g, h) * w) * 4u);
+        };
+        issue_into(nxb, i0 + G + R, i0 + G < i1);
+        // iterations in pairs; when the strip has an odd number of them the last one finds all its
+        // rows past the strip and stores nothing
+        for (int ii = i0; ii < i1; ii += 2 * G) {
+            iteration(ii, 0, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1); }, SaTrue{});
+            iteration(ii + G, NBUF - 1, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1); }, SaTrue{});
+        }
+    } else {
+        int buf = 0;
+        for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
+            finish_rows();
+            iteration(ii, buf, nx, [&] { if (ii + G < i1) issue_rows(ii + G + R); }, SaFalse{});
+        }
     }
 #ifdef SA_BLUR_CLOCK
     if (tid == 0 && !OVS) {
