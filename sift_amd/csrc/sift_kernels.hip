@@ -236,7 +236,11 @@ __device__ __forceinline__ float ovs_sample(__amdgpu_buffer_rsrc_t img, int wi, 
     if (ip >= hi) ip = 2 * hi - 1 - ip;
     if (im >= hi) im = 2 * hi - 1 - im;
     const float fx = x - floorf(x);
-    const unsigned rp = (unsigned)(ip * wi) * 4u, rm = (unsigned)(im * wi) * 4u;
+    // the row is the same for the whole wave (a thread is a column), but it comes out of float
+    // arithmetic, which runs on the vector unit: name the row offsets wave-uniform, or every load
+    // gets a loop over the distinct values of its scalar offset
+    const unsigned rp = __builtin_amdgcn_readfirstlane((unsigned)(ip * wi) * 4u);
+    const unsigned rm = __builtin_amdgcn_readfirstlane((unsigned)(im * wi) * 4u);
     const float a = buf_ld(img, c.jp * 4u, rp), b = buf_ld(img, c.jm * 4u, rp);
     const float cc = buf_ld(img, c.jp * 4u, rm), d = buf_ld(img, c.jm * 4u, rm);
     const float top = __fadd_rn(__fmul_rn(c.fy, a), __fmul_rn(1 - c.fy, b));
@@ -677,6 +681,7 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
                                          float* l_tmp, float* l_prev, float* ring)
 {
     constexpr int NG = (EW - 2 * HA) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
+    constexpr unsigned OOB = 0x80000000u;       // lane offset past the descriptor's range: the access is dropped
     const __amdgpu_buffer_rsrc_t src = buf_rsrc(in_img), r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img);
     const int col = mirror_idx(g.X0 + tid, g.w);
     const unsigned ucol = (unsigned)col * 4u;
@@ -694,54 +699,75 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
         return buf_ld(src, ucol, (unsigned)(r * g.w) * 4u);
     };
     v2f wp[NP];
-    float nx[G];
-    // Prefetch of the next 8 rows.  With the oversampling at step 1/2, rows 2m and 2m+1 interpolate
-    // the same two input rows: their horizontally interpolated rows are loaded once (raw samples
-    // issued here, interpolation at the top of the next iteration); rows that need mirroring take
-    // the per-sample path (same expressions as k_blur_fused).
+    // The 8 source rows of an iteration are fetched two iterations ahead, into two register sets used
+    // in turn: when an iteration waits for its rows, the loads of the following iteration are younger
+    // than them, so the wait (vmcnt retires loads and stores in issue order) never extends to the
+    // stores the wave has just issued.  Every iteration issues its loads; rows nobody will use get an
+    // out-of-range lane offset.  With the oversampling at step 1/2, rows 2m and 2m+1 interpolate the
+    // same two input rows: their horizontally interpolated rows are loaded once (raw samples issued
+    // by issue(), interpolation in take() two iterations later); rows that need mirroring take the
+    // per-sample path (same expressions as k_blur_fused).
+    struct RowSet { float nx[G]; float raw[OVS ? 2 * (G / 2 + 2) : 1]; bool pending, odd; };
     const bool half_step = OVS && delta == 0.5f;
-    float raw[OVS ? 2 * (G / 2 + 2) : 1];
-    bool raw_pending = false, raw_odd = false;
-    auto issue_rows = [&](int ifirst) {
-        if (OVS && half_step && ifirst >= 0 && ifirst + G - 1 < g.h && ((ifirst + G - 1) >> 1) + 1 < hi) {
-            const int m = ifirst >> 1;
-            raw_odd = ifirst & 1;
+    auto issue = [&](RowSet& rs, int ifirst, bool live) {
+        const bool shared = OVS && half_step && ifirst >= 0 && ifirst + G - 1 < g.h && ((ifirst + G - 1) >> 1) + 1 < hi;
+        if (OVS && (shared || !live)) {
+            const int m = shared ? ifirst >> 1 : 0;
+            rs.odd = ifirst & 1;
+            const unsigned jp = live ? oc.jp * 4u : OOB, jm = live ? oc.jm * 4u : OOB;
 #pragma unroll
             for (int t = 0; t < G / 2 + 2; ++t) {
                 const unsigned rp = (unsigned)(min(m + t, hi - 1) * wi) * 4u;
-                raw[OVS ? 2 * t : 0] = buf_ld(src, oc.jp * 4u, rp);
-                raw[OVS ? 2 * t + 1 : 0] = buf_ld(src, oc.jm * 4u, rp);
+                rs.raw[OVS ? 2 * t : 0] = buf_ld(src, jp, rp);
+                rs.raw[OVS ? 2 * t + 1 : 0] = buf_ld(src, jm, rp);
             }
-            raw_pending = true;
-        } else {
-            raw_pending = false;
+            rs.pending = true;
+        } else if (OVS) {
+            rs.pending = false;
 #pragma unroll
-            for (int q = 0; q < G; ++q) nx[q] = load(ifirst + q);
+            for (int q = 0; q < G; ++q) rs.nx[q] = load(ifirst + q);
+        } else {
+            rs.pending = false;
+            const unsigned lane = live ? ucol : OOB;
+#pragma unroll
+            for (int q = 0; q < G; ++q) rs.nx[q] = buf_ld(src, lane, (unsigned)(mirror_idx(ifirst + q, g.h) * g.w) * 4u);
         }
     };
-    auto finish_rows = [&]() {
-        if (!OVS || !raw_pending) return;
-        float H[G / 2 + 2];
+    // the set's rows into the top of the column window
+    auto take = [&](RowSet& rs) {
+        if (OVS && rs.pending) {
+            float H[G / 2 + 2];
 #pragma unroll
-        for (int t = 0; t < G / 2 + 2; ++t)
-            H[t] = __fadd_rn(__fmul_rn(oc.fy, raw[OVS ? 2 * t : 0]), __fmul_rn(1 - oc.fy, raw[OVS ? 2 * t + 1 : 0]));
-        // row ifirst + q: input rows (ifirst + q) / 2 and the next one, weight 1/2 on odd rows
-        if (raw_odd) {
+            for (int t = 0; t < G / 2 + 2; ++t)
+                H[t] = __fadd_rn(__fmul_rn(oc.fy, rs.raw[OVS ? 2 * t : 0]), __fmul_rn(1 - oc.fy, rs.raw[OVS ? 2 * t + 1 : 0]));
+            // row ifirst + q: input rows (ifirst + q) / 2 and the next one, weight 1/2 on odd rows
+            float v[G];
+            if (rs.odd) {
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int t = (q + 1) >> 1;
-                const float fx = ((q + 1) & 1) ? 0.5f : 0.f;
-                nx[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+                for (int q = 0; q < G; ++q) {
+                    const int t = (q + 1) >> 1;
+                    const float fx = ((q + 1) & 1) ? 0.5f : 0.f;
+                    v[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < G; ++q) {
+                    const int t = q >> 1;
+                    const float fx = (q & 1) ? 0.5f : 0.f;
+                    v[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+                }
             }
-        } else {
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-                const int t = q >> 1;
-                const float fx = (q & 1) ? 0.5f : 0.f;
-                nx[q] = __fadd_rn(__fmul_rn(fx, H[t + 1]), __fmul_rn(1 - fx, H[t]));
+            for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{v[2 * q], v[2 * q + 1]};
+        } else {
+            // asm moves: the copies out of the load registers stay here, where only this set's loads
+            // have to be complete, instead of becoming register copies at the loop's back edge
+#pragma unroll
+            for (int q = 0; q < G / 2; ++q) {
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wp[R + q].x) : "v"(rs.nx[2 * q]));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wp[R + q].y) : "v"(rs.nx[2 * q + 1]));
             }
         }
-        raw_pending = false;
     };
     {
         float pro[2 * R];
@@ -750,22 +776,19 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = v2f{pro[2 * t], pro[2 * t + 1]};
     }
-    issue_rows(r0 + R);
-    int buf = 0;
-    for (int j = 0; j < g.n_iter; ++j, buf ^= 1) {
+    // iteration j stores rows r0 + 8j ..., if its rows still reach the consumer before the consumer's
+    // last iteration (j + 2 < n_iter); n_iter is even
+    auto iteration = [&](int j, int buf, RowSet& rs) {
         const int ii = r0 + G * j;
-        // the rows of the last two iterations would reach the consumer after its last iteration
         const bool work = j + 2 < g.n_iter;
-        finish_rows();
-#pragma unroll
-        for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
-        if (j + 3 < g.n_iter) issue_rows(ii + G + R);
+        take(rs);
+        issue(rs, ii + 2 * G + R, j + 4 < g.n_iter);
         float* tmp = l_tmp + buf * G * PITCH;
         float* prev = l_prev + (PREV ? buf * G * PITCH : 0);
         if (work) col_pass<R, PITCH, PREV>(wp, tp, tmp, prev, tid);
         __syncthreads();
         if (work) {
-            float* slot = ring + (j & 1) * G * PITCH;
+            float* slot = ring + buf * G * PITCH;
 #pragma unroll
             for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
                 const int item = rnd * EW + tid;
@@ -782,6 +805,13 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
         }
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+    };
+    RowSet ra, rb;
+    issue(ra, r0 + R, true);
+    issue(rb, r0 + G + R, 3 < g.n_iter);
+    for (int j = 0; j < g.n_iter; j += 2) {
+        iteration(j, 0, ra);
+        iteration(j + 1, 1, rb);
     }
 }
 
@@ -858,7 +888,7 @@ k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __re
     g.i0 = by * strip; g.i1 = min(g.i0 + strip, h);
     g.cells_w = (w + 63) >> 6;
     const int warm = 2 + (RB + 3) / 4;
-    g.n_iter = warm + (g.i1 - g.i0 + G - 1) / G;
+    g.n_iter = (warm + (g.i1 - g.i0 + G - 1) / G + 1) & ~1;     // even: the producer walks its iterations in pairs
     const int r0b = g.i0 - G * warm, r0a = r0b + RB + 16;
     int* flags_img = flags ? flags + b * ((h + 7) >> 3) * (long long)g.cells_w : nullptr;
     if (role == 0)
