@@ -2100,9 +2100,18 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
     // sequentially, so small octaves get short strips to keep enough blocks in flight
     static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
-    int strip = EW == 512 ? (a.ovs_w > 0 ? 256 : 128) : 64;    // (the oversampling prologue is the costliest)
+    int strip = EW == 512 ? 256 : 64;
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
+    if (EW == 512 && a.ovs_w == 0) {
+        // plain wide launches: the image cut into equal strips of about 512 rows (measured for 128 1080p
+        // images, R = 10 / 13: 1.93 / 2.19 ms with 128-row strips, 1.87 / 2.14 ms with 544), more of them
+        // while there are too few blocks
+        int n = (a.h + 256) / 512 > 0 ? (a.h + 256) / 512 : 1;
+        auto rows = [&](int parts) { return (((a.h + parts - 1) / parts) + 7) & ~7; };
+        while (rows(n) > 16 && cols * ((a.h + rows(n) - 1) / rows(n)) * a.batch * 2 < 2048) n *= 2;
+        strip = rows(n);
+    }
     if (forced > 0) strip = (forced + 7) & ~7;     // the kernel relies on strips of whole 8-row groups
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
     float* out = a.out;
