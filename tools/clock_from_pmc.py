@@ -11,7 +11,7 @@ import sys
 
 def main():
     d = sys.argv[1]
-    min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 4000000
+    min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 2000000
     files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(list)
     for f in files:

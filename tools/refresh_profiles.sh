@@ -5,10 +5,10 @@ set -e
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-# octave-0 blur launch of 128 1080p images (the bench's batch): 8 x 17 tiles of 480 x 128 outputs
+# octave-0 blur launch of 128 1080p images (the bench's batch): 8 x 4 tiles of 480 x 544 outputs
 # per image, 512 threads
 BATCH=128
-DOM_BLOCKS=$((8 * 17 * BATCH))
+DOM_BLOCKS=$((8 * 4 * BATCH))
 DOM_THREADS=512
 # the radius-5/7 pair of octave 0 as one launch: 8 x 2 tiles of 480 x 1080 outputs per image, 1024 threads
 PAIR_BLOCKS=$((8 * 2 * BATCH))
