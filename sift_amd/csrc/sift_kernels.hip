@@ -2099,7 +2099,8 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     constexpr int TW = EW - 32;
     // strip height: tall strips amortise the 2R-row prologue, but every block walks its strip
     // sequentially, so small octaves get short strips to keep enough blocks in flight
-    static const int forced = getenv("SIFT_AMD_STRIP") ? atoi(getenv("SIFT_AMD_STRIP")) : 0;
+    const char* fs = getenv("SIFT_AMD_STRIP");          // forces a strip height (tests, A/B runs)
+    const int forced = fs ? atoi(fs) : 0;
     int strip = EW == 512 ? 256 : 64;
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;

@@ -71,6 +71,10 @@ def test_hip_reproduces_golden(hip, name):
 SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
             {"SIFT_AMD_PAIR": "0"},       # every blur a launch of its own (no two-blur launches)
             {"SIFT_AMD_PAIR_STRIP": "64"},   # two-blur launches forced, in short strips
+            {"SIFT_AMD_STRIP": "72"},     # single-blur launches in strips of 9 iterations: rows fetched two
+                                          # iterations ahead, the last iteration of a strip is an empty one
+            {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "544"},   # the same path with tall strips, every radius
+            {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "72"},
             {"SIFT_AMD_GRAPH": "0"},      # no hipGraph replay
             {"SIFT_AMD_DEBUG": "1"},      # generic descriptor instantiation
             {"SIFT_AMD_DEBUG": "2"},      # descriptor contributions listed per cell instead of per bin
