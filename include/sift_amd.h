@@ -163,9 +163,11 @@ void save_pairs_extra(const char* name, const struct sift_keypoints* k1,
  * Devices and streams: every entry point runs on the context's device and leaves the calling
  * thread's current HIP device as it found it.  A `stream` argument must belong to the context's
  * device.  The runs of one context share its pool, so they execute one after the other: a run
- * queued on another stream than the previous run first waits for the previous run.  When a
- * list of a run overflows its capacity, every call that reads that run's results returns -2
- * until the next run. */
+ * queued on another stream than the previous run first waits, on the device, for the previous
+ * run.  The library does not touch a caller's stream after the call that received it has
+ * returned (later runs and readers wait for an event of the context), so the caller may destroy
+ * the stream at any time.  When a list of a run overflows its capacity, every call that reads
+ * that run's results returns -2 until the next run. */
 
 typedef struct sift_amd_ctx sift_amd_ctx;
 
@@ -298,7 +300,11 @@ int sift_amd_match_images(sift_amd_ctx* ctx, int img_a, int img_b, float thresh,
  * minima) is a fixed 5.3 MB array inside the library's code object, one copy per GPU.
  * Limits: n1, n2 <= 8192, dim <= 256, n2 >= 2; anything larger is refused with an error.
  * Runs on the calling thread's current device; work is queued on `stream` (hipStream_t as
- * void*, NULL = the null stream) and the results are valid once the stream has caught up.
+ * void*) and the results are valid once the stream has caught up.  NULL means the legacy null
+ * stream, the only place where this library touches it (creating a stream would be an
+ * allocation): the null stream synchronises with every blocking stream of the process and a
+ * launch on it fails while another host thread captures a hipGraph, so callers with more than
+ * one thread should pass a stream created with hipStreamNonBlocking.
  * Returns 0 when queued, a negative value on error.  Every call on one GPU uses that GPU's one
  * scratch array: calls that overlap on a GPU (different streams without ordering) race; calls
  * on one stream are ordered.  The first call on a device looks up the array's device address
@@ -327,6 +333,21 @@ int sift_amd_profile_read(sift_amd_ctx* ctx, int kernel_class, int octave /* -1 
  * that writes image `scale` of the Gaussian stack of `octave` (scale 0 = the seed launch). */
 int sift_amd_profile_read_blur(sift_amd_ctx* ctx, int octave, int scale, double* ms, long long* launches,
                                int reset);
+
+/* Test aid: how many blur launches of this process took which route since the last reset
+ * (a hipGraph replay launches nothing and counts nothing).  out has SIFT_AMD_LS_COUNT entries. */
+enum {
+    SIFT_AMD_LS_PAIR_SEED = 0,          /* two-blur launches: oversampled seed + first blur */
+    SIFT_AMD_LS_PAIR,                   /* two-blur launches of two stack images */
+    SIFT_AMD_LS_PAIR_STRIP_MAX,         /* tallest strip (rows) of any two-blur launch */
+    SIFT_AMD_LS_WIDE_AHEAD2,            /* single-blur launches, 480-column tiles, rows fetched two iterations ahead */
+    SIFT_AMD_LS_WIDE_AHEAD2_STRIP_MAX,  /* their tallest strip */
+    SIFT_AMD_LS_WIDE_OTHER,             /* other 480-column-tile launches (seed blur, short strips) */
+    SIFT_AMD_LS_NARROW,                 /* 224-column-tile launches */
+    SIFT_AMD_LS_SPARSE,                 /* launches of the last stack image that skipped unread regions */
+    SIFT_AMD_LS_COUNT
+};
+int sift_amd_launch_stats(long long* out, int reset);
 
 #ifdef __cplusplus
 }

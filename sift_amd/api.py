@@ -94,6 +94,7 @@ def lib():
     L.sift_amd_match_u8_noalloc.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_float, C.c_int,
                                             vp, vp, vp, vp, vp, vp]
     L.sift_amd_release_thread_cache.restype = None
+    L.sift_amd_launch_stats.argtypes = [P(C.c_longlong), C.c_int]
     _lib = L
     return L
 
@@ -104,6 +105,17 @@ def _err(what):
 
 def device_count():
     return lib().sift_amd_device_count()
+
+
+LAUNCH_STATS = ["pair_seed", "pair", "pair_strip_max", "wide_ahead2", "wide_ahead2_strip_max",
+                "wide_other", "narrow", "sparse"]
+
+
+def launch_stats(reset=False):
+    """Routes the blur launches of this process took since the last reset (dict name -> count)."""
+    out = (C.c_longlong * len(LAUNCH_STATS))()
+    lib().sift_amd_launch_stats(out, int(reset))
+    return dict(zip(LAUNCH_STATS, out[:]))
 
 
 def valu_ceiling(device=0, reps=3):

@@ -154,7 +154,11 @@ struct sift_amd_ctx {
     BlurSpec seed;
     BlurSpec step[SA_MAX_OCT][SA_MAX_SCA];
     hipStream_t own_stream = nullptr;
-    hipStream_t last_stream = nullptr;
+    // Recorded behind every run on the stream the run was queued on.  The next run and every
+    // reader wait for it on their own stream (hipStreamWaitEvent: ordering on the device, no host
+    // block), so a caller's stream is never touched after the call that received it has returned;
+    // the caller may destroy it.
+    hipEvent_t run_done = nullptr;
     int last_n = 0;
 
     // d_seed (oversampled input) and d_tmp (column-pass image) only exist when some blur radius is
@@ -224,8 +228,24 @@ struct sift_amd_ctx {
 static hipError_t sa_copy(sift_amd_ctx* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
 {
     if (!bytes) return hipSuccess;
+    DeviceGuard dev_guard_(c->device);
+    if (!dev_guard_.ok) return hipErrorInvalidDevice;
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->own_stream);
     return e != hipSuccess ? e : hipStreamSynchronize(c->own_stream);
+}
+
+// The context's own stream, ordered behind the last run (whatever stream that was queued on).
+static hipError_t own_stream_after_run(sift_amd_ctx* c)
+{
+    return hipStreamWaitEvent(c->own_stream, c->run_done, 0);
+}
+
+// Called behind the last launch of a run.  Inside a capture nothing is recorded: the event is
+// recorded behind the graph's launch instead.
+static hipError_t mark_run_end(sift_amd_ctx* c, hipStream_t st)
+{
+    if (c->capturing) return hipSuccess;
+    return hipEventRecord(c->run_done, st);
 }
 
 template <typename T>
@@ -315,8 +335,10 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
         }
 
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) {
-        sa_set_error("hipStreamCreate failed");
+        hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->run_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(c->run_done, c->own_stream) != hipSuccess) {
+        sa_set_error("hipStreamCreate / hipEventCreate failed");
         return fail();
     }
 
@@ -440,7 +462,7 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
 {
     if (!c) return;
     DeviceGuard dev_guard_(c->device);
-    if (c->last_stream) (void)hipStreamSynchronize(c->last_stream);
+    if (c->run_done) (void)hipEventSynchronize(c->run_done);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& e : c->prof_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : c->prof_pool) hipEventDestroy(e);
@@ -450,6 +472,7 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
         delete g;
     }
     if (c->capture_stream) hipStreamDestroy(c->capture_stream);
+    if (c->run_done) hipEventDestroy(c->run_done);
     for (void* v : c->allocs) hipFree(v);
     if (c->d_u8) hipFree(c->d_u8);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -570,6 +593,7 @@ static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, int sca, const Blur
 
 int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st)
 {
+    SA_ON_DEVICE(c);
     const SaLayout& L = c->L;
     const int ns = L.n_sca;
     // Cell marks let the extrema scan skip regions without any contrast-passing sample.  They
@@ -656,11 +680,13 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("scale-space launch failed: %s", hipGetErrorString(e)); return -1; }
+    HIP_TRY(mark_run_end(c, st));
     return 0;
 }
 
 int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
 {
+    SA_ON_DEVICE(c);
     const SaLayout& L = c->L;
     HIP_TRY(hipMemsetAsync(c->d_counters, 0, (size_t)n * SA_CNT_STRIDE * sizeof(int), st));
     const int emit_all = (c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) ? 1 : 0;
@@ -681,6 +707,7 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
       sa::launch_rank(st, c->d_skey, c->d_sidx, c->d_counters, c->d_flist, c->fcap, n); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("detection launch failed: %s", hipGetErrorString(e)); return -1; }
+    HIP_TRY(mark_run_end(c, st));
     return 0;
 }
 
@@ -688,6 +715,7 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
 // d_flist) or caller-supplied keys (d_given).
 int sa_run_orient(sift_amd_ctx* c, int n, hipStream_t st, bool given, int mode)
 {
+    SA_ON_DEVICE(c);
     const SaKey* keys = given ? c->d_given : c->d_ref;
     const int* index = given ? nullptr : c->d_flist;
     const int kcap = given ? c->fcap : c->cap;
@@ -699,16 +727,19 @@ int sa_run_orient(sift_amd_ctx* c, int n, hipStream_t st, bool given, int mode)
                         c->d_keys, c->d_key_src, c->kcap, n); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("orientation launch failed: %s", hipGetErrorString(e)); return -1; }
+    HIP_TRY(mark_run_end(c, st));
     return 0;
 }
 
 int sa_run_describe(sift_amd_ctx* c, int n, hipStream_t st)
 {
+    SA_ON_DEVICE(c);
     ProfScope ps(c, st, SIFT_AMD_K_DESCRIPTOR, 0);
     sa::launch_descriptor(st, c->pyr, c->sc, c->d_keys, c->d_counters, SA_CNT_KEYS, c->kcap, c->d_std, c->d_descr, n);
     if (n > 1) sa::launch_pack_std(st, c->d_std, c->d_counters, SA_CNT_KEYS, c->kcap, c->d_packed, n);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { sa_set_error("descriptor launch failed: %s", hipGetErrorString(e)); return -1; }
+    HIP_TRY(mark_run_end(c, st));
     return 0;
 }
 
@@ -717,10 +748,10 @@ static hipStream_t pick_stream(sift_amd_ctx* c, void* stream) { return stream ? 
 static int begin_run(sift_amd_ctx* c, int n, hipStream_t st)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
-    // runs of one context share its pool: a run queued on another stream than the previous one
-    // waits for the previous one
-    if (c->last_stream && c->last_stream != st) HIP_TRY(hipStreamSynchronize(c->last_stream));
-    c->last_stream = st; c->last_n = n; c->counters_valid = false; c->overflowed = false;
+    // runs of one context share its pool: a run waits, on the device, for the previous one,
+    // whatever stream that was queued on
+    HIP_TRY(hipStreamWaitEvent(st, c->run_done, 0));
+    c->last_n = n; c->counters_valid = false; c->overflowed = false;
     return 0;
 }
 
@@ -781,6 +812,7 @@ static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_
         c->graphs.push_back(g);
     }
     HIP_TRY(hipGraphLaunch(g->exec, st));
+    HIP_TRY(mark_run_end(c, st));
     return 0;
 }
 
@@ -804,6 +836,7 @@ extern "C" int sift_amd_detect_host(sift_amd_ctx* c, const float* images, int n)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
     SA_ON_DEVICE(c);
+    HIP_TRY(own_stream_after_run(c));          // the previous run may still be reading the input buffer
     HIP_TRY(hipMemcpyAsync(c->d_in, images, (size_t)n * c->im_w * c->im_h * sizeof(float),
                            hipMemcpyHostToDevice, c->own_stream));
     return sift_amd_detect_device(c, c->d_in, n, nullptr);
@@ -830,7 +863,9 @@ extern "C" int sift_amd_detect_host_u8(sift_amd_ctx* c, const unsigned char* ima
     if (channels != 1 && channels != 3 && channels != 4) { sa_set_error("channels must be 1, 3 or 4 (got %d)", channels); return -1; }
     SA_ON_DEVICE(c);
     const size_t bytes = (size_t)n * c->im_w * c->im_h * channels;
+    HIP_TRY(own_stream_after_run(c));          // the previous run may still be reading the staging buffer
     if (bytes > c->d_u8_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->own_stream));
         if (c->d_u8) HIP_TRY(hipFree(c->d_u8));
         c->d_u8 = nullptr; c->d_u8_bytes = 0;
         HIP_TRY(hipMalloc((void**)&c->d_u8, bytes));
@@ -844,8 +879,7 @@ extern "C" int sift_amd_copy_ingested(sift_amd_ctx* c, int n, float* dst)
 {
     if (n < 1 || n > c->batch) { sa_set_error("batch %d outside 1..%d", n, c->batch); return -1; }
     SA_ON_DEVICE(c);
-    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(own_stream_after_run(c));
     HIP_TRY(sa_copy(c, dst, c->d_in, (size_t)n * c->im_w * c->im_h * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -853,7 +887,7 @@ extern "C" int sift_amd_copy_ingested(sift_amd_ctx* c, int n, float* dst)
 int sa_ctx_image_keys(sift_amd_ctx* c, int img, const void** d_std, const float** d_descr, int* n, int* n_descr)
 {
     if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     *n = c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS];
     *d_std = c->d_std + (size_t)img * c->kcap;
     *d_descr = c->d_descr + (size_t)img * c->kcap * SA_MAX_DESCR;
@@ -865,7 +899,8 @@ int sa_sync_counters(sift_amd_ctx* c)
 {
     SA_ON_DEVICE(c);
     if (!c->counters_valid) {
-        hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+        hipStream_t st = c->own_stream;
+        HIP_TRY(own_stream_after_run(c));
         HIP_TRY(hipMemcpyAsync(c->h_counters, c->d_counters, (size_t)c->batch * SA_CNT_STRIDE * sizeof(int),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -899,7 +934,7 @@ extern "C" int sift_amd_fetch_keypoints(sift_amd_ctx* c, int img, sift_keypoint_
                                         sift_amd_key* out_keys, int max_keys)
 {
     if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS], max_keys);
     if (n > 0 && out_std)
         HIP_TRY(sa_copy(c, out_std, c->d_std + (size_t)img * c->kcap, (size_t)n * sizeof(SaStd), hipMemcpyDeviceToHost));
@@ -910,7 +945,7 @@ extern "C" int sift_amd_fetch_keypoints(sift_amd_ctx* c, int img, sift_keypoint_
 
 extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** out, int* counts)
 {
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     size_t total = 0;
     for (int b = 0; b < c->last_n; b++) {
         counts[b] = c->h_counters[b * SA_CNT_STRIDE + SA_CNT_KEYS];
@@ -918,7 +953,8 @@ extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** ou
     }
     sift_keypoint_std* buf = (sift_keypoint_std*)malloc(std::max<size_t>(total, 1) * sizeof(sift_keypoint_std));
     if (!buf) { sa_set_error("out of host memory"); return -1; }
-    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    SA_ON_DEVICE(c);
+    hipStream_t st = c->own_stream;            // already ordered behind the run by sa_sync_counters
     // one copy: the records were packed image after image on the device (k_pack_std)
     const SaStd* src = c->last_n > 1 ? c->d_packed : c->d_std;
     if (total) HIP_TRY(hipMemcpyAsync(buf, src, total * sizeof(SaStd), hipMemcpyDeviceToHost, st));
@@ -929,7 +965,7 @@ extern "C" int sift_amd_gather_keypoints(sift_amd_ctx* c, sift_keypoint_std** ou
 
 extern "C" int sift_amd_gather_keypoints_into(sift_amd_ctx* c, sift_keypoint_std* out, int max_records, int* counts)
 {
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     SA_ON_DEVICE(c);
     size_t total = 0;
     for (int b = 0; b < c->last_n; b++) {
@@ -940,7 +976,7 @@ extern "C" int sift_amd_gather_keypoints_into(sift_amd_ctx* c, sift_keypoint_std
         sa_set_error("gather buffer holds %d records, the batch has %zu", max_records, total);
         return -1;
     }
-    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
+    hipStream_t st = c->own_stream;            // already ordered behind the run by sa_sync_counters
     const SaStd* src = c->last_n > 1 ? c->d_packed : c->d_std;
     if (total) HIP_TRY(hipMemcpyAsync(out, src, total * sizeof(SaStd), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -992,31 +1028,46 @@ __global__ void __launch_bounds__(256) k_valu_ceiling(float* out, int iters)
     if (s == 12345.678f) out[0] = s;
 }
 
+// Both probes run on a non-blocking stream of their own (never the legacy default stream, see sa_copy).
+struct ProbeStream {
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = false;
+    ProbeStream()
+    {
+        ok = hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+             hipEventCreate(&e1) == hipSuccess;
+    }
+    ~ProbeStream()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
 extern "C" int sift_amd_valu_ceiling(int device, int reps, double* lane_gops)
 {
     DeviceGuard dev_guard_(device);
     if (!dev_guard_.ok) return -1;
     float* d = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProbeStream ps;
     int rc = -1;
     float ms = 0.f;
     const int iters = 4096, blocks = 256 * 16;     // 16 waves per SIMD in total, 4 resident at a time
     do {
-        if (hipMalloc((void**)&d, 256) != hipSuccess) break;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-        hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters);
-        if (hipDeviceSynchronize() != hipSuccess) break;
-        (void)hipEventRecord(e0, nullptr);
+        if (!ps.ok || hipMalloc((void**)&d, 256) != hipSuccess) break;
+        hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, ps.s, d, iters);
+        if (hipStreamSynchronize(ps.s) != hipSuccess) break;
+        (void)hipEventRecord(ps.e0, ps.s);
         for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, nullptr, d, iters);
-        (void)hipEventRecord(e1, nullptr);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+            hipLaunchKernelGGL(k_valu_ceiling, dim3(blocks), dim3(256), 0, ps.s, d, iters);
+        (void)hipEventRecord(ps.e1, ps.s);
+        if (hipEventSynchronize(ps.e1) != hipSuccess || hipEventElapsedTime(&ms, ps.e0, ps.e1) != hipSuccess) break;
         *lane_gops = (double)blocks * 256 * iters * 32.0 * reps / (ms * 1e-3) / 1e9;
         rc = 0;
     } while (0);
     if (rc) sa_set_error("valu ceiling: %s", hipGetErrorString(hipGetLastError()));
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     if (d) (void)hipFree(d);
     return rc;
 }
@@ -1028,29 +1079,34 @@ extern "C" int sift_amd_copy_ceiling(int device, size_t bytes, int reps, double*
     if (bytes < (1u << 20) || reps < 1) { sa_set_error("copy ceiling: need >= 1 MiB and >= 1 repetition"); return -1; }
     const size_t n = bytes / 16;
     void *a = nullptr, *b = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProbeStream ps;
     int rc = -1;
     float ms = 0.f;
+    g_err[0] = 0;
     do {
+        if (!ps.ok) break;
         if (hipMalloc(&a, n * 16) != hipSuccess || hipMalloc(&b, n * 16) != hipSuccess) { sa_set_error("copy ceiling: hipMalloc failed"); break; }
-        if (hipMemset(a, 1, n * 16) != hipSuccess || hipMemset(b, 0, n * 16) != hipSuccess) break;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
-        hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, nullptr, (const sa_v4f*)a, (sa_v4f*)b, n);
-        if (hipDeviceSynchronize() != hipSuccess) break;
-        (void)hipEventRecord(e0, nullptr);
+        if (hipMemsetAsync(a, 1, n * 16, ps.s) != hipSuccess || hipMemsetAsync(b, 0, n * 16, ps.s) != hipSuccess) break;
+        hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, ps.s, (const sa_v4f*)a, (sa_v4f*)b, n);
+        if (hipStreamSynchronize(ps.s) != hipSuccess) break;
+        (void)hipEventRecord(ps.e0, ps.s);
         for (int r = 0; r < reps; ++r)
-            hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, nullptr, (const sa_v4f*)a, (sa_v4f*)b, n);
-        (void)hipEventRecord(e1, nullptr);
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+            hipLaunchKernelGGL(k_copy_ceiling, dim3(16384), dim3(256), 0, ps.s, (const sa_v4f*)a, (sa_v4f*)b, n);
+        (void)hipEventRecord(ps.e1, ps.s);
+        if (hipEventSynchronize(ps.e1) != hipSuccess || hipEventElapsedTime(&ms, ps.e0, ps.e1) != hipSuccess) break;
         *gb_per_s = 2.0 * (double)(n * 16) * reps / (ms * 1e-3) / 1e9;
         rc = 0;
     } while (0);
-    if (rc && !sift_amd_last_error()[0]) sa_set_error("copy ceiling: %s", hipGetErrorString(hipGetLastError()));
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
+    if (rc && !g_err[0]) sa_set_error("copy ceiling: %s", hipGetErrorString(hipGetLastError()));
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     return rc;
+}
+
+extern "C" int sift_amd_launch_stats(long long* out, int reset)
+{
+    sa::launch_stats(out, reset);
+    return 0;
 }
 
 extern "C" int sift_amd_stage_counts(sift_amd_ctx* c, int img, int stage_sizes[6], int ext_oct[SIFT_AMD_MAX_OCT])
@@ -1072,7 +1128,7 @@ extern "C" int sift_amd_fetch_candidates(sift_amd_ctx* c, int img, sift_amd_key*
                                          int* stage, int max_n)
 {
     if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     const int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_CAND], c->cap);
     if (!seed && !refined && !stage) return n;
     std::vector<unsigned long long> key(n);
@@ -1117,8 +1173,7 @@ extern "C" int sift_amd_copy_scalespace(sift_amd_ctx* c, int img, int which, int
         return -1;
     }
     SA_ON_DEVICE(c);
-    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(own_stream_after_run(c));
     const long long np = (long long)c->L.w[o] * c->L.h[o];
     const int nimg = which == 0 ? c->L.n_sca : c->L.n_sca - 1;
     const float* src = (which == 0 ? c->d_gss[o] : c->d_dog[o]) + (long long)img * nimg * np;
@@ -1130,7 +1185,7 @@ extern "C" int sift_amd_fetch_extras(sift_amd_ctx* c, int img, float* orihist, f
                                      int max_keys)
 {
     if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     const int n = std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_KEYS], max_keys);
     const int nb = c->p.n_bins, nd = c->p.n_hist * c->p.n_hist * c->p.n_ori;
     if (n && descr) {
@@ -1155,7 +1210,7 @@ extern "C" int sift_amd_fetch_extras(sift_amd_ctx* c, int img, float* orihist, f
 extern "C" int sift_amd_fetch_stage_f_histograms(sift_amd_ctx* c, int img, float* orihist, int max_n)
 {
     if (img < 0 || img >= c->last_n) { sa_set_error("image index %d out of range", img); return -1; }
-    if (sa_sync_counters(c)) return -1;
+    if (const int rc_ = sa_sync_counters(c)) return rc_;     // -2: a list of the run overflowed
     const int nf = std::min(std::min(c->h_counters[img * SA_CNT_STRIDE + SA_CNT_NF], c->fcap), max_n);
     const int nb = c->p.n_bins;
     if (nf && orihist) {
@@ -1175,9 +1230,10 @@ int sa_describe_given(sift_amd_ctx* c, const SaKey* keys, int n, bool find_orien
     if (n > c->fcap) { sa_set_error("too many keypoints (%d > %d)", n, c->fcap); return -1; }
     SA_ON_DEVICE(c);
     hipStream_t st = c->own_stream;
-    c->last_stream = st; c->last_n = 1; c->counters_valid = false; c->overflowed = false;
+    c->last_n = 1; c->counters_valid = false; c->overflowed = false;
     int cnt[SA_CNT_STRIDE] = {0};
     cnt[SA_CNT_NF] = n; cnt[SA_CNT_KEYS] = n;
+    HIP_TRY(own_stream_after_run(c));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(sa_copy(c, c->d_counters, cnt, sizeof cnt, hipMemcpyHostToDevice));
     if (find_orientation) {
@@ -1212,7 +1268,7 @@ hipStream_t sa_ctx_stream(sift_amd_ctx* c) { return c->own_stream; }
 const float* sa_ctx_stack(sift_amd_ctx* c, int which, int o)
 {
     if (o < 0 || o >= c->L.n_oct || which < 0 || which > 1 || (which == 1 && !c->d_dog[o])) return nullptr;
-    hipStream_t st = c->last_stream ? c->last_stream : c->own_stream;
-    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    DeviceGuard dev_guard_(c->device);
+    if (!dev_guard_.ok || hipEventSynchronize(c->run_done) != hipSuccess) return nullptr;
     return which == 0 ? c->d_gss[o] : c->d_dog[o];
 }

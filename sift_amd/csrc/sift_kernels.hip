@@ -2087,6 +2087,22 @@ k_pack_std(const SaStd* __restrict__ std_recs, const int* __restrict__ counters,
 
 namespace sa {
 
+// Which route the blur launches of this process took (tests assert that the route they mean to
+// exercise really ran; a hipGraph replay launches nothing and counts nothing).
+static long long g_launch_stats[SIFT_AMD_LS_COUNT];
+static void ls_add(int k, long long v = 1) { __atomic_fetch_add(&g_launch_stats[k], v, __ATOMIC_RELAXED); }
+static void ls_max(int k, long long v)
+{
+    long long cur = __atomic_load_n(&g_launch_stats[k], __ATOMIC_RELAXED);
+    while (cur < v && !__atomic_compare_exchange_n(&g_launch_stats[k], &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+void launch_stats(long long* out, int reset)
+{
+    for (int k = 0; k < SIFT_AMD_LS_COUNT; ++k)
+        out[k] = reset ? __atomic_exchange_n(&g_launch_stats[k], 0, __ATOMIC_RELAXED)
+                       : __atomic_load_n(&g_launch_stats[k], __ATOMIC_RELAXED);
+}
+
 #define SA_R_CASES(F) \
     case 1: F(1); break; case 2: F(2); break; case 3: F(3); break; case 4: F(4); break; \
     case 5: F(5); break; case 6: F(6); break; case 7: F(7); break; case 8: F(8); break; \
@@ -2115,6 +2131,12 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     }
     if (forced > 0) strip = (forced + 7) & ~7;     // the kernel relies on strips of whole 8-row groups
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
+    if (EW == 512 && a.ovs_w == 0 && strip >= 64) {      // the kernel's two-iterations-ahead branch
+        ls_add(SIFT_AMD_LS_WIDE_AHEAD2);
+        ls_max(SIFT_AMD_LS_WIDE_AHEAD2_STRIP_MAX, strip);
+    } else {
+        ls_add(EW == 512 ? SIFT_AMD_LS_WIDE_OTHER : SIFT_AMD_LS_NARROW);
+    }
     float* out = a.out;
     SaTapPairs tp2;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
@@ -2148,7 +2170,7 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
     // 4 waves): whichever covers the image width with fewer columns in total.  The wide tile has
     // the smaller halo share and fewer idle row-pass slots (~5 % on octave 0 of a 1080p image) but
     // wastes most of a tile on narrow octaves.  SIFT_AMD_WIDE_MIN=<width> forces the choice by width.
-    static const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 0;
+    const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 0;
     const bool wide = wide_min > 0 ? a.w >= wide_min
                                    : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
     if (wide) blur_fused_launch<R, 512, 2>(st, a);
@@ -2199,6 +2221,8 @@ bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe)
         if (probe) return true;                                                                               \
         constexpr int TWS = 512 - 2 * (((RA + 3) & ~3) + ((RB + 3) & ~3));                                    \
         const int nbx = (a.w + TWS - 1) / TWS, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch; \
+        ls_add(OVS ? SIFT_AMD_LS_PAIR_SEED : SIFT_AMD_LS_PAIR);                                               \
+        ls_max(SIFT_AMD_LS_PAIR_STRIP_MAX, strip);                                                            \
         HIPK((k_blur_pair<RA, RB, FA, FB, OVS, SUB>), dim3(nblocks), dim3(1024), 0, st, a.in, a.out_a, a.out_b, a.sub, \
              a.w, a.h, a.s_in, a.s_a, a.s_b, a.s_sub, ta, tb, strip, nbx, nby, nblocks, a.ovs_w, a.ovs_h,      \
              a.ovs_delta, a.flags, a.flag_thr);                                                               \

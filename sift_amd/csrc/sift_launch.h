@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "../../include/sift_amd.h"
 #include "sift_dev.h"
 
 struct sift_amd_ctx;
@@ -73,6 +74,8 @@ void launch_expand(hipStream_t st, const SaKey* keys, const int* index, int* cou
 void launch_descriptor(hipStream_t st, const SaPyramid& P, const SaScalars& sc, const SaKey* keys,
                        const int* counters, int cnt_slot, int kcap, SaStd* out_std, float* out_descr,
                        int batch);
+
+void launch_stats(long long* out, int reset);   // SIFT_AMD_LS_* counters of this process
 
 void launch_pack_std(hipStream_t st, const SaStd* std_recs, const int* counters, int cnt_slot, int kcap,
                      SaStd* packed, int batch);

@@ -341,7 +341,8 @@ void run_u8(hipStream_t st, const U8Plan& pl, const unsigned char* d1, long long
 int match_device(hipStream_t st, bool is_u8, const void* d1, long long stride1, int n1, const void* d2, long long stride2,
                  int n2, int dim, float thresh, int flag, int* iA, int* iB, float* dA, float* dB, unsigned char* pass)
 {
-    if (n1 < 0 || n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
+    if (n1 < 0) { sa_set_error("negative number of query descriptors (%d)", n1); return -1; }
+    if (n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
     if (dim < 1 || dim > SA_MAX_DESCR) { sa_set_error("descriptor length %d outside 1..%d", dim, SA_MAX_DESCR); return -1; }
     if (n1 == 0) return 0;
     DevBuf q8, t8, nq, nt, tt, part, o_ia, o_ib, o_da, o_db, o_pass;
@@ -387,7 +388,8 @@ int match_device(hipStream_t st, bool is_u8, const void* d1, long long stride1, 
 int match_host(int device, bool is_u8, const void* h1, int n1, const void* h2, int n2, int dim, float thresh, int flag,
                int* iA, int* iB, float* dA, float* dB, unsigned char* pass)
 {
-    if (n1 < 0 || n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
+    if (n1 < 0) { sa_set_error("negative number of query descriptors (%d)", n1); return -1; }
+    if (n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
     if (dim < 1 || dim > SA_MAX_DESCR) { sa_set_error("descriptor length %d outside 1..%d", dim, SA_MAX_DESCR); return -1; }
     if (n1 == 0) return 0;
     HIP_TRY(hipSetDevice(device));
@@ -464,7 +466,8 @@ extern "C" int sift_amd_match_u8_noalloc(const unsigned char* d_desc1, int n1, c
                                          int dim, float thresh, int flag, int* d_iA, int* d_iB, float* d_dA,
                                          float* d_dB, unsigned char* d_pass, void* stream)
 {
-    if (n1 < 0 || n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
+    if (n1 < 0) { sa_set_error("negative number of query descriptors (%d)", n1); return -1; }
+    if (n2 < 2) { sa_set_error("matching needs at least two target descriptors (got %d)", n2); return -1; }
     if (dim < 1 || dim > SA_NA_MAX_DIM) { sa_set_error("descriptor length %d outside 1..%d", dim, SA_NA_MAX_DIM); return -1; }
     if (n1 > SA_NA_MAX_N || n2 > SA_NA_MAX_N) {
         sa_set_error("allocation-free matching takes at most %d descriptors per set (got %d and %d)", SA_NA_MAX_N, n1, n2);

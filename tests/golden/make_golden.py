@@ -7,7 +7,8 @@ stores only data: digests of the inputs and of every scale-space octave, stage s
 octave, scalar tables, and -- for the small cases -- the full final keypoint table.
 Only runs where /root/reference is present; the outputs are committed.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 # everything
+    python tests/golden/make_golden.py NAME [NAME ...]   # only these cases; the index keeps the others
 """
 import hashlib
 import json
@@ -39,6 +40,12 @@ CASES = [
     ("smooth_1920x1080", "smooth", 1920, 1080, 12345, {}, False),
     ("white_1920x1080", "white", 1920, 1080, 12345, {}, False),
     ("smooth_3840x2160", "smooth", 3840, 2160, 12345, {}, False),
+    # octaves 960 and 480 wide: the widths at which single-blur launches pick 480-column tiles
+    ("white_480x270", "white", 480, 270, 7, {}, True),
+    ("natural_480x270", "natural", 480, 270, 3, {}, True),
+    # full-size stand-in for a photograph, and the keypoint-dense case at 4K
+    ("natural_1920x1080", "natural", 1920, 1080, 12345, {}, False),
+    ("white_3840x2160", "white", 3840, 2160, 12345, {}, False),
 ]
 
 
@@ -49,7 +56,16 @@ def digest(a):
 def main():
     lib = refrun.ref_lib()
     index = {}
+    only = set(sys.argv[1:])
+    if only:
+        unknown = only - {c[0] for c in CASES}
+        if unknown:
+            sys.exit(f"unknown case(s): {sorted(unknown)}")
+        with open(os.path.join(HERE, "index.json")) as f:
+            index = json.load(f)
     for name, kind, w, h, seed, kw, table in CASES:
+        if only and name not in only:
+            continue
         img = synth.make(kind, w, h, seed)
         p = abi.SiftParameters.default().copy(**kw)
         rec = refrun.run_sift_anatomy(lib, img, p, keep_ss=True)
@@ -61,6 +77,9 @@ def main():
             "dims": [[o["w"], o["h"]] for o in rec["octaves"]],
             "sigmas": [[float(s).hex() for s in o["sigmas"]] for o in rec["octaves"]],
             "gss_sha1": [digest(g) for g in rec["gss"]],
+            # per image of the stack: the batched pipeline may leave the last image of an octave,
+            # which only the refinement reads near a candidate, incomplete
+            "gss_image_sha1": [[digest(im) for im in g] for g in rec["gss"]],
             "dog_sha1": [digest(d) for d in rec["dog"]],
             "stage_counts_per_octave": {
                 s: refrun.counts_per_octave(rec["stages"][s]["ints"], n_oct).tolist() for s in "ABCDEF"},

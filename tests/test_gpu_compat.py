@@ -217,10 +217,17 @@ def test_c_matching_host_program(hip, tmp_path):
 def test_concurrent_host_threads(hip):
     """The reference is re-entrant (no globals); the replacement must be too: four host threads
     call the reference-named sift_compute_features and a batched context of their own at the
-    same time, on different images, and get what a single thread gets."""
+    same time, on different images, and get what a single thread gets.  Every thread also calls
+    the allocation-free matcher on a non-blocking stream of its own while the others capture
+    their hipGraphs (its calls share one scratch array per GPU, so they take turns under a lock)."""
     import threading
+    from test_matching import FIELDS, assert_same, descriptor_sets
+    from test_zz_no_alloc import DTYPES, Hip
     w, h, n_threads, rounds = 240, 180, 4, 3
     imgs = [synth.make("white", w, h, seed=900 + t) for t in range(n_threads)]
+    sets = [descriptor_sets(200 + 10 * t, 300, 128, 70 + t, "u8") for t in range(n_threads)]
+    want_match = [api.match(a, b, 0.6, 1) for a, b in sets]
+    scratch_lock = threading.Lock()
 
     def flat(img):
         return api.sift_compute_features(img)
@@ -230,14 +237,29 @@ def test_concurrent_host_threads(hip):
             ctx.detect_host(np.stack([img, img]))
             return ctx.keypoints(1)[0].tobytes()
 
+    def noalloc(t, hipm, stream):
+        a, b = sets[t]
+        da, db = hipm.upload(a), hipm.upload(b)
+        out = {f: hipm.alloc(len(a) * np.dtype(DTYPES[f]).itemsize) for f in FIELDS}
+        with scratch_lock:
+            rc = hip.sift_amd_match_u8_noalloc(da, len(a), db, len(b), 128, 0.6, 1, *(out[f] for f in FIELDS), stream)
+            assert rc == 0, hip.sift_amd_last_error().decode()
+            assert hipm.rt.hipStreamSynchronize(stream) == 0
+        res = {f: hipm.download(out[f], len(a), DTYPES[f]) for f in FIELDS}
+        hipm.free_all()
+        return res
+
     want = [(flat(im).tobytes(), batched(im)) for im in imgs]
     errors = []
 
     def worker(t):
         try:
+            hipm = Hip(own_stream=True)
+            stream = hipm.own
             for _ in range(rounds):
                 assert flat(imgs[t]).tobytes() == want[t][0]
                 assert batched(imgs[t]) == want[t][1]
+                assert_same(noalloc(t, hipm, stream), want_match[t], f"thread {t}")
             hip.sift_amd_release_thread_cache()
         except BaseException as e:       # noqa: BLE001 - reported to the main thread
             errors.append((t, repr(e)))
@@ -249,6 +271,33 @@ def test_concurrent_host_threads(hip):
         th.join()
     assert not errors, errors
     assert len(want[0][0]) > 144 * 20
+
+
+def test_runs_on_streams_the_caller_destroys(hip):
+    """A context keeps no handle of a caller's stream: run on stream A, destroy A, run on stream B
+    (per-request streams of a serving loop), read the results, destroy the context."""
+    from test_zz_no_alloc import Hip
+    w, h = 200, 150
+    img = synth.white(w, h, 3)
+    hipm = Hip()
+    d_img = hipm.upload(np.stack([img, img]))
+    with sift_amd.Context(w, h, max_batch=2) as ref:
+        ref.detect_host(np.stack([img, img]))
+        want = ref.keypoints(1)[0].tobytes()
+    ctx = sift_amd.Context(w, h, max_batch=2)
+    for k in range(4):
+        s = hipm.stream(non_blocking=(k % 2 == 0))
+        ctx.detect_device(d_img, 2, s)
+        if k % 2 == 0:
+            assert hipm.rt.hipStreamSynchronize(s) == 0
+        hipm.rt.hipStreamDestroy(s)       # with work of the run possibly still queued on it (odd k)
+        if k >= 2:
+            assert ctx.keypoints(1)[0].tobytes() == want
+    s = hipm.stream(non_blocking=True)
+    ctx.detect_device(d_img, 2, s)
+    hipm.rt.hipStreamDestroy(s)
+    ctx.close()                            # waits for the last run without the stream
+    hipm.free_all()
 
 
 def test_reference_named_calls_grow_their_lists_instead_of_aborting(hip, monkeypatch):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import sift_amd
-from sift_amd import abi, synth
+from sift_amd import abi, api, synth
 
 from test_oracle_golden import GOLD, INDEX, digest
 
@@ -71,10 +71,13 @@ def test_hip_reproduces_golden(hip, name):
 SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
             {"SIFT_AMD_PAIR": "0"},       # every blur a launch of its own (no two-blur launches)
             {"SIFT_AMD_PAIR_STRIP": "64"},   # two-blur launches forced, in short strips
-            {"SIFT_AMD_STRIP": "72"},     # single-blur launches in strips of 9 iterations: rows fetched two
-                                          # iterations ahead, the last iteration of a strip is an empty one
+            # single-blur launches in strips of 9 iterations; on octaves that take 480-column tiles
+            # (the 480x270 cases: 960 and 480 wide) rows are then fetched two iterations ahead and the
+            # last iteration of a strip is an empty one
+            {"SIFT_AMD_STRIP": "72"},
             {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "544"},   # the same path with tall strips, every radius
             {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "72"},
+            {"SIFT_AMD_WIDE_MIN": "300", "SIFT_AMD_STRIP": "64"},   # 480-column tiles forced on every octave >= 300 wide
             {"SIFT_AMD_GRAPH": "0"},      # no hipGraph replay
             {"SIFT_AMD_DEBUG": "1"},      # generic descriptor instantiation
             {"SIFT_AMD_DEBUG": "2"},      # descriptor contributions listed per cell instead of per bin
@@ -82,7 +85,8 @@ SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
 
 
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-@pytest.mark.parametrize("name", ["white_200x150", "natural_800x640_a", "white_333x257_spo4"])
+@pytest.mark.parametrize("name", ["white_200x150", "natural_800x640_a", "white_333x257_spo4", "white_480x270",
+                                  "natural_480x270"])
 def test_diagnostic_switches_give_the_same_records(hip, monkeypatch, name, env):
     e = INDEX[name]
     img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
@@ -90,9 +94,22 @@ def test_diagnostic_switches_give_the_same_records(hip, monkeypatch, name, env):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    api.launch_stats(reset=True)
     with sift_amd.Context(e["w"], e["h"], 2, p) as ctx:
-        for _ in range(3):                                    # plain launches, graph build, replay
+        for rep in range(3):                                  # plain launches, graph build, replay
             ctx.detect_host(np.stack([img, img]))
+            if rep == 0:
+                # the switch reached the route it is meant to exercise
+                st = api.launch_stats(reset=True)
+                wide = any(((w + 479) // 480) * 512 < ((w + 223) // 224) * 256 for w, _ in ctx.dims)
+                if "SIFT_AMD_WIDE_MIN" in env:
+                    wide = ctx.dims[0][0] >= 300
+                if "SIFT_AMD_STRIP" in env and wide:
+                    assert st["wide_ahead2"] > 0 and st["wide_ahead2_strip_max"] == ((int(env["SIFT_AMD_STRIP"]) + 7) & ~7), st
+                if env.get("SIFT_AMD_PAIR") == "0":
+                    assert st["pair"] == 0 and st["pair_seed"] == 0, st
+                if "SIFT_AMD_PAIR_STRIP" in env and ctx.dims[0][0] >= 900 and ctx.dims[0][0] % 4 == 0:
+                    assert st["pair_seed"] == 1 and st["pair"] >= 1 and st["pair_strip_max"] == 64, st
             for b in range(2):
                 std, keys = ctx.keypoints(b)
                 orih, descr, _ = ctx.extras(b)

@@ -7,6 +7,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from oracle import pyoracle
+
 from test_matching import FIELDS, assert_same, descriptor_sets, with_ties
 
 
@@ -15,39 +17,60 @@ class Hip:
     second HIP runtime into the process, as importing torch after the library would, leaves the
     second one without GPUs)."""
 
-    def __init__(self):
+    def __init__(self, own_stream=False):
+        """own_stream: copies and fills go through a non-blocking stream of this object instead of
+        the legacy default stream (which fails while another host thread captures a hipGraph)."""
         self.rt = C.CDLL("libamdhip64.so.7")
         self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.rt.hipFree.argtypes = [C.c_void_p]
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.rt.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.rt.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        self.rt.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.rt.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.rt.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
         assert self.rt.hipSetDevice(0) == 0
         self.bufs = []
+        self.own = self.stream(non_blocking=True) if own_stream else None
 
     def alloc(self, nbytes, fill=0xA5):
         p = C.c_void_p()
         assert self.rt.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
-        assert self.rt.hipMemset(p, fill, max(nbytes, 16)) == 0
+        if self.own:
+            assert self.rt.hipMemsetAsync(p, fill, max(nbytes, 16), self.own) == 0
+            assert self.rt.hipStreamSynchronize(self.own) == 0
+        else:
+            assert self.rt.hipMemset(p, fill, max(nbytes, 16)) == 0
         self.bufs.append(p)
         return p
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         p = self.alloc(arr.nbytes)
-        assert self.rt.hipMemcpy(p, arr.ctypes.data, arr.nbytes, 1) == 0
+        self._copy(p, arr.ctypes.data, arr.nbytes, 1)
         return p
+
+    def _copy(self, dst, src, nbytes, kind):
+        if self.own:
+            assert self.rt.hipMemcpyAsync(dst, src, nbytes, kind, self.own) == 0
+            assert self.rt.hipStreamSynchronize(self.own) == 0
+        else:
+            assert self.rt.hipMemcpy(dst, src, nbytes, kind) == 0
 
     def download(self, p, n, dtype):
         out = np.empty(n, dtype)
         if n:
-            assert self.rt.hipMemcpy(out.ctypes.data, p, out.nbytes, 2) == 0
+            self._copy(out.ctypes.data, p, out.nbytes, 2)
         return out
 
-    def stream(self):
+    def stream(self, non_blocking=False):
         s = C.c_void_p()
-        assert self.rt.hipStreamCreate(C.byref(s)) == 0
+        if non_blocking:
+            assert self.rt.hipStreamCreateWithFlags(C.byref(s), 1) == 0      # hipStreamNonBlocking
+        else:
+            assert self.rt.hipStreamCreate(C.byref(s)) == 0
         return s
 
     def sync(self):
@@ -90,6 +113,9 @@ def test_noalloc_matching_equals_allocating_entry_point(hip):
         want = api.match(a, b, thresh, flag)
         got = _noalloc(hip, hipm, a, b, thresh, flag, stream)
         assert_same(got, want, f"noalloc {n1}x{n2}x{dim}")
+        if n1 <= 3000:         # and directly against the CPU oracle (the 8192 x 8192 case takes it minutes)
+            assert_same(got, pyoracle.matching(a.astype(np.float32), b.astype(np.float32), thresh, flag),
+                        f"noalloc vs oracle {n1}x{n2}x{dim}")
         assert n1 < 1000 or want["pass"].sum() > 100
     hipm.rt.hipStreamDestroy(s)
 
