@@ -199,6 +199,12 @@ struct sift_amd_ctx {
     struct GraphEntry {
         const float* d_images; int n; unsigned prof_mask; int what;
         hipGraphExec_t exec; std::vector<ProfEvent> events;
+        hipGraph_t graph = nullptr;     // kept for the lifetime of exec
+        ~GraphEntry()
+        {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+        }
     };
     bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
     bool use_cells = true;          // SIFT_AMD_CELLS=0: the extrema scan visits every sample
@@ -419,7 +425,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
             off[o + 1] = off[o] + (size_t)B * ((L->h[o] + 7) / 8) * ((L->w[o] + 63) / 64);
         c->cells_total = off[L->n_oct];
         int* cells = nullptr;
-        if (dev_alloc(c, &cells, c->cells_total)) return fail();
+        if (dev_alloc(c, &cells, (c->cells_total + 3) & ~(size_t)3)) return fail();    // cleared in 16-byte words
         for (int o = 0; o < L->n_oct; o++) c->d_cells[o] = cells + off[o];
     }
     if (dev_alloc(c, &c->d_flist, (size_t)(B * c->fcap))) return fail();
@@ -468,7 +474,6 @@ extern "C" void sift_amd_destroy(sift_amd_ctx* c)
     for (auto& e : c->prof_pool) hipEventDestroy(e);
     for (auto* g : c->graphs) {
         for (auto& e : g->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-        if (g->exec) hipGraphExecDestroy(g->exec);
         delete g;
     }
     if (c->capture_stream) hipStreamDestroy(c->capture_stream);
@@ -599,7 +604,7 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
     // Cell marks let the extrema scan skip regions without any contrast-passing sample.  They
     // are of no use when every discrete extremum has to be listed.
     const bool mark = !(c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) && c->use_cells;
-    if (mark) HIP_TRY(hipMemsetAsync(c->d_cells[0], 0, c->cells_total * sizeof(int), st));
+    if (mark) sa::launch_clear_words(st, c->d_cells[0], (long long)c->cells_total);
     for (int o = 0; o < L.n_oct; o++) {
         c->cells_valid[o] = mark;
         const long long np = (long long)L.w[o] * L.h[o];
@@ -688,7 +693,7 @@ int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st)
 {
     SA_ON_DEVICE(c);
     const SaLayout& L = c->L;
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, (size_t)n * SA_CNT_STRIDE * sizeof(int), st));
+    sa::launch_clear_words(st, c->d_counters, (long long)n * SA_CNT_STRIDE);
     const int emit_all = (c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) ? 1 : 0;
     for (int o = 0; o < L.n_oct; o++) {
         const long long np = (long long)L.w[o] * L.h[o];
@@ -788,7 +793,6 @@ static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_
             auto* old = c->graphs.front();
             c->graphs.erase(c->graphs.begin());
             for (auto& e : old->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-            if (old->exec) hipGraphExecDestroy(old->exec);
             delete old;
         }
         g = new sift_amd_ctx::GraphEntry{d_images, n, c->prof_mask, what, nullptr, {}};
@@ -801,7 +805,7 @@ static int run_graphed(sift_amd_ctx* c, const float* d_images, int n, hipStream_
             ok = hipStreamEndCapture(c->capture_stream, &graph) == hipSuccess && rc == 0 && graph;
         }
         if (ok) ok = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) hipGraphDestroy(graph);
+        g->graph = graph;
         if (!ok) {
             (void)hipGetLastError();
             for (auto& e : g->events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -914,7 +918,9 @@ int sa_sync_counters(sift_amd_ctx* c)
     if (c->overflowed) {
         for (int b = 0; b < c->last_n; b++)
             if (c->h_counters[b * SA_CNT_STRIDE + SA_CNT_OVERFLOW]) {
-                sa_set_error("candidate/keypoint list overflow on image %d (capacity %d/%d/%d)", b, c->cap, c->fcap, c->kcap);
+                const int* q = c->h_counters + b * SA_CNT_STRIDE;
+                sa_set_error("candidate/keypoint list overflow on image %d: %d candidates, %d survivors, %d keypoints "
+                             "(capacity %d/%d/%d)", b, q[SA_CNT_CAND], q[SA_CNT_SURV], q[SA_CNT_KEYS], c->cap, c->fcap, c->kcap);
                 break;
             }
         return -2;

@@ -191,6 +191,17 @@ k_ingest_u8(const unsigned char* __restrict__ in, float* __restrict__ out, long 
     else for (int e = 0; p0 + e < n_px; e++) out[p0 + e] = g[e];
 }
 
+// Zeroes n 32-bit words (n a multiple of 4, the buffer 16-byte aligned).  The pipeline clears its
+// marks and counters with this kernel instead of hipMemsetAsync: a memset node of a captured
+// hipGraph was seen to replay with the arguments of an unrelated later fill/copy of the process
+// (ROCm 7.2: the counters of a context held another copy's operands after a graph replay that
+// followed small host<->device copies on the null stream), a kernel node keeps its own.
+__global__ void __launch_bounds__(256) k_clear_words(unsigned* __restrict__ p, long long n)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < n) *reinterpret_cast<v4u*>(__builtin_assume_aligned(p + i, 16)) = v4u{0u, 0u, 0u, 0u};
+}
+
 // lib_discrete.c:180-191
 __global__ void __launch_bounds__(256)
 k_subsample2(const float* __restrict__ in, int wi, long long s_in,
@@ -2256,6 +2267,13 @@ void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass)
     else
         HIPK(k_blur_h_any, grid, dim3(256), 0, st, a.tmp, a.in, a.out, a.dog, a.w, a.h,
              a.s_tmp, a.s_in, a.s_out, a.s_dog, a.taps_dev, a.radius);
+}
+
+void launch_clear_words(hipStream_t st, void* p, long long n_words)
+{
+    const long long n = (n_words + 3) & ~3ll;          // allocations are rounded up by the caller
+    if (n <= 0) return;
+    HIPK(k_clear_words, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (unsigned*)p, n);
 }
 
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,

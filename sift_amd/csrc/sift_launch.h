@@ -49,6 +49,7 @@ struct BlurPairArgs {
 bool launch_blur_pair(hipStream_t st, const BlurPairArgs& a, bool probe = false);
 void launch_blur_pass(hipStream_t st, const BlurArgs& a, int pass);
 bool launch_blur_fused(hipStream_t st, const BlurArgs& a);
+void launch_clear_words(hipStream_t st, void* p, long long n_words);   // n_words rounded up to a multiple of 4
 void launch_oversample(hipStream_t st, const float* in, int wi, int hi, long long s_in,
                        float* out, int wo, int ho, long long s_out, float delta, int batch);
 void launch_ingest_u8(hipStream_t st, const unsigned char* in, int channels, float* out, long long n_px);

@@ -98,6 +98,34 @@ def test_run_to_run_determinism(hip):
     assert len(runs[0]) > 144 * 100 and all(r == runs[0] for r in runs)
 
 
+def test_graph_replay_between_foreign_copies(hip):
+    """A context's cached hipGraphs replayed after other users of the process have issued small
+    fills and host<->device copies on the null stream (what a torch tensor created on the GPU or an
+    .item() does), two input buffers in turn: same bytes every time.  (A memset node inside a
+    captured graph replayed with the operands of such a later copy; the pipeline clears its buffers
+    with a kernel of its own since.)"""
+    from test_zz_no_alloc import Hip
+    w, h, B = 400, 300, 4
+    imgs = np.stack([synth.make("white", w, h, seed=40 + b) for b in range(B)])
+    hipm = Hip()
+    d_a, d_b = hipm.upload(imgs), hipm.upload(imgs)
+    small = hipm.alloc(4096)
+    host = np.arange(64, dtype=np.float64)
+    with sift_amd.Context(w, h, max_batch=B) as ctx:
+        want = None
+        for k in range(14):
+            ctx.detect_device(d_a if k % 2 == 0 else d_b, B, None)
+            got = ctx.gather()[0].tobytes()
+            want = want or got
+            assert got == want, f"run {k}"
+            for r in range(k % 5 + 1):                       # foreign null-stream traffic between the runs
+                assert hipm.rt.hipMemcpy(small, host.ctypes.data, 8 * (r + 1), 1) == 0
+                assert hipm.rt.hipMemset(small, r, 64) == 0
+                assert hipm.rt.hipMemcpy(host.ctypes.data, small, 8 * (r + 1), 2) == 0
+    assert len(want) > 144 * 400
+    hipm.free_all()
+
+
 EDGE_IMAGES = {
     "constant": lambda w, h: np.full((h, w), 0.37, np.float32),
     "zeros": lambda w, h: np.zeros((h, w), np.float32),
