@@ -21,7 +21,10 @@ void sa_layout_lowe(SaLayout* L, int n_oct, int n_spo, int im_w, int im_h, float
 
 sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batch, const sift_parameters* p,
                                     const SaLayout* L, float sigma_in, int flags, int cap_req, int fcap_req);
-int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st);
+// whole_stack: every image of every stack is computed everywhere.  Without it a context that keeps
+// neither the DoG stacks nor every extremum computes the last image of an octave only where the
+// extrema scan and the refinement of the same run can read it.
+int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, bool whole_stack = true);
 int sa_run_detect(sift_amd_ctx* c, int n, hipStream_t st);
 int sa_run_orient(sift_amd_ctx* c, int n, hipStream_t st, bool given, int mode);
 int sa_run_describe(sift_amd_ctx* c, int n, hipStream_t st);

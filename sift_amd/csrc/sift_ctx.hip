@@ -209,6 +209,7 @@ struct sift_amd_ctx {
     bool use_graph = true;          // SIFT_AMD_GRAPH=0 launches kernel by kernel
     bool use_cells = true;          // SIFT_AMD_CELLS=0: the extrema scan visits every sample
     bool use_pairs = true;          // SIFT_AMD_PAIR=0: every blur is a launch of its own
+    bool use_sparse = true;         // SIFT_AMD_SPARSE=0: the last image of every stack is computed everywhere
     std::vector<GraphEntry*> graphs;
     // keys launched eagerly once: a graph is built when a key comes back, so callers that pass a
     // new buffer every time do not pay a capture per call
@@ -333,6 +334,7 @@ sift_amd_ctx* sa_create_from_layout(int device, int im_w, int im_h, int max_batc
     if (const char* m = getenv("SIFT_AMD_GRAPH")) c->use_graph = atoi(m) != 0;
     if (const char* m = getenv("SIFT_AMD_CELLS")) c->use_cells = atoi(m) != 0;
     if (const char* m = getenv("SIFT_AMD_PAIR")) c->use_pairs = atoi(m) != 0;
+    if (const char* m = getenv("SIFT_AMD_SPARSE")) c->use_sparse = atoi(m) != 0;
 
     for (int o = 1; o < L->n_oct; o++)
         if (L->w[o] != L->w[o - 1] / 2 || L->h[o] != L->h[o - 1] / 2) {
@@ -573,10 +575,10 @@ extern "C" int sift_amd_profile_read_blur(sift_amd_ctx* c, int octave, int scale
 // sca: index, within the octave's Gaussian stack, of the image this blur writes
 static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, int sca, const BlurSpec& b, const float* in, long long s_in,
                      float* out, long long s_out, float* dog, long long s_dog, float* sub, long long s_sub, int n,
-                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, int* cells = nullptr)
+                     int ovs_w = 0, int ovs_h = 0, float ovs_delta = 0.f, int* cells = nullptr, const int* need_cells = nullptr)
 {
     sa::BlurArgs a;
-    a.flags = cells; a.flag_thr = c->sc.thr_pre;
+    a.flags = cells; a.flag_thr = c->sc.thr_pre; a.need_cells = need_cells;
     a.ovs_w = ovs_w; a.ovs_h = ovs_h; a.ovs_delta = ovs_delta;
     a.in = in; a.tmp = c->d_tmp; a.out = out; a.dog = dog; a.sub = sub;
     a.s_in = s_in; a.s_tmp = (long long)c->L.w[0] * c->L.h[0]; a.s_out = s_out; a.s_dog = s_dog; a.s_sub = s_sub;
@@ -596,7 +598,7 @@ static void run_blur(sift_amd_ctx* c, hipStream_t st, int o, int sca, const Blur
     }
 }
 
-int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st)
+int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, bool whole_stack)
 {
     SA_ON_DEVICE(c);
     const SaLayout& L = c->L;
@@ -604,6 +606,8 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
     // Cell marks let the extrema scan skip regions without any contrast-passing sample.  They
     // are of no use when every discrete extremum has to be listed.
     const bool mark = !(c->flags & SIFT_AMD_KEEP_ALL_EXTREMA) && c->use_cells;
+    // the last image of a stack only where it can be read (see k_blur_fused, SPARSE)
+    const bool sparse_last = mark && !whole_stack && c->use_sparse && !(c->flags & SIFT_AMD_KEEP_SCALESPACE);
     if (mark) sa::launch_clear_words(st, c->d_cells[0], (long long)c->cells_total);
     for (int o = 0; o < L.n_oct; o++) {
         c->cells_valid[o] = mark;
@@ -679,8 +683,10 @@ int sa_run_scalespace(sift_amd_ctx* c, const float* d_images, int n, hipStream_t
                 if (c->step[o][s].radius >= 1 && c->step[o][s].radius <= SA_MAX_RADIUS_FAST) cells = c->d_cells[o];
                 else c->cells_valid[o] = false;
             }
+            // the marks of all centre scales are complete when the last image's launch starts (same stream)
+            const int* need = (sparse_last && s == ns - 1 && c->cells_valid[o] && !sub && !cells) ? c->d_cells[o] : nullptr;
             run_blur(c, st, o, s, c->step[o][s], g + (s - 1) * np, sg, g + s * np, sg, d ? d + (s - 1) * np : nullptr, sd, sub, s_sub, n,
-                     0, 0, 0.f, cells);
+                     0, 0, 0.f, cells, need);
         }
     }
     hipError_t e = hipGetLastError();
@@ -763,7 +769,7 @@ static int begin_run(sift_amd_ctx* c, int n, hipStream_t st)
 // what: 0 = scale-space only, 1 = whole pipeline
 static int run_sequence(sift_amd_ctx* c, const float* d_images, int n, hipStream_t st, int what)
 {
-    if (sa_run_scalespace(c, d_images, n, st)) return -1;
+    if (sa_run_scalespace(c, d_images, n, st, what == 0)) return -1;
     if (what == 0) return 0;
     if (sa_run_detect(c, n, st)) return -1;
     if (sa_run_orient(c, n, st, false, 0)) return -1;

@@ -299,13 +299,22 @@ extern "C" void sift_amd_debug_blur_clock(unsigned long long* out, int reset)
 
 // PREV = false: no DoG epilogue (dog and flags are null), the buffer of unfiltered centre samples
 // does not exist and a block needs half the LDS.
-template <int R, bool OVS, int EW, int NBUF, bool VW, bool PREV>
+// SPARSE: the image is computed only where it can be read.  The last image of an octave's stack
+// feeds nothing but the last DoG image, which the extrema scan and the refinement read only next to
+// a sample that passed the first contrast test (lib_sift_anatomy.c:240-313, 358-405: a scan
+// neighbour is 1 sample away, a refined position at most 4 moves plus one tap, so at most 6), and
+// the marks of the 8 x 64 cells holding such samples (`need_cells`) are complete before this launch
+// starts.  A block evaluates an 8-row group of its tile only if a cell within 6 samples of it is
+// marked; the other rows of `out` keep whatever they held.  Strips have at most 64 groups.
+template <int R, bool OVS, int EW, int NBUF, bool VW, bool PREV, bool SPARSE = false>
 __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
              float* __restrict__ sub, int w, int h, long long s_in, long long s_out,
              long long s_dog, long long s_sub, SaTapPairs tp, int strip, int nbx, int nby, int nblocks,
-             int wi, int hi, float delta, int* __restrict__ flags, float flag_thr)
+             int wi, int hi, float delta, int* __restrict__ flags, float flag_thr,
+             const int* __restrict__ need_cells)
 {
+    static_assert(!SPARSE || (!OVS && !PREV && VW && NBUF == 2), "sparse form: plain launches only");
     // LDS rows are padded to 288 floats: with 16-byte reads at a 16-byte lane stride this makes
     // the row pass free of bank conflicts also where a wave straddles two rows.
     constexpr int G = 8, RP = 16, TW = EW - 2 * RP, NG = TW / 4, PITCH = EW + 32;
@@ -341,8 +350,45 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         if (OVS) return ovs_sample(src, wi, hi, delta, r, oc);
         return buf_ld(src, ucol, (unsigned)(r * w) * 4u);
     };
-    const int i0 = by * strip;
-    const int i1 = min(i0 + strip, h);
+    int i0 = by * strip;
+    int i1 = min(i0 + strip, h);
+    // SPARSE: bit j of `need` = the j-th 8-row group of the strip is evaluated; bit j of `fetch` = the
+    // source rows that enter the column window in iteration j are used by an evaluated group
+    unsigned long long need = ~0ull, fetch = ~0ull;
+    if constexpr (SPARSE) {
+        __shared__ unsigned long long l_need;
+        if (tid == 0) l_need = 0;
+        __syncthreads();
+        const int cw = (w + 63) >> 6, ch = (h + 7) >> 3;
+        const int* cells = need_cells + b * (long long)ch * cw;
+        const int g0 = i0 >> 3, ng = (i1 - i0 + 7) >> 3;
+        const int c0 = max((x0 - 6) >> 6, 0), c1 = min((min(x0 + TW, w) + 5) >> 6, cw - 1);
+        const int ncol = c1 - c0 + 1;
+        const unsigned long long strip_mask = ng >= 64 ? ~0ull : (1ull << ng) - 1;
+        for (int t = tid; t < (ng + 2) * ncol; t += EW) {
+            const int gr = t / ncol, cc = t - gr * ncol;      // cell row g0 - 1 + gr
+            const int cr = g0 - 1 + gr;
+            if (cr >= 0 && cr < ch && cells[cr * cw + c0 + cc]) {
+                // a marked cell row needs its own group of rows and the two next to it: groups gr-2 .. gr of the strip
+                const unsigned long long m = (gr >= 2 ? 7ull << (gr - 2) : 7ull >> (2 - gr)) & strip_mask;
+                if (m) atomicOr(&l_need, m);
+            }
+        }
+        __syncthreads();
+        const unsigned long long nd = l_need;
+        need = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(nd >> 32)) << 32) |
+               __builtin_amdgcn_readfirstlane((unsigned)nd);
+        if (need == 0) return;
+        // the strip shrinks to the span between its first and last needed group
+        const int lead = __builtin_ctzll(need);
+        i0 += 8 * lead;
+        need >>= lead;
+        i1 = min(i1, i0 + 8 * (64 - __builtin_clzll(need)));
+        fetch = need;
+#pragma unroll
+        for (int k = 1; k <= (2 * R + 7) / 8; ++k) fetch |= need >> k;
+    }
+    auto bit = [](unsigned long long m, int j) { return j < 64 && ((m >> j) & 1ull); };
     // VW: the launcher guarantees w % 4 == 0, every 4-sample item is then a whole 16-byte access
     const bool vec_w = VW || (w & 3) == 0;
     const int wo = w >> 1, ho = h >> 1;
@@ -455,7 +501,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 
     // One iteration: 8 rows of the strip starting at row ii.  nxr holds their newest source rows,
     // prefetch() starts the loads of a later iteration once nxr has been taken into the window.
-    auto iteration = [&](int ii, int buf, float (&nxr)[G], auto&& prefetch, auto pinned) {
+    auto iteration = [&](int ii, int buf, float (&nxr)[G], auto&& prefetch, auto pinned, bool run) {
         if constexpr (decltype(pinned)::value) {
             // asm moves: the copies out of the load registers stay here, where only these rows' loads
             // have to be complete, instead of becoming register copies at the loop's back edge
@@ -469,7 +515,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             for (int q = 0; q < G / 2; ++q) { wp[R + q].x = nxr[2 * q]; wp[R + q].y = nxr[2 * q + 1]; }
         }
         prefetch();
-        if (NBUF == 1) __syncthreads();
+        if (!SPARSE || run) {
         // two output pairs at a time: the two accumulation chains are independent, so a wave has a
         // second instruction to issue while the first one's result is on its way
 #pragma unroll
@@ -566,6 +612,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 }
             }
         }
+        }   // run
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
     };
@@ -583,18 +630,33 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
             for (int g = 0; g < G; ++g) dst[g] = buf_ld(src, lane, (unsigned)(mirror_idx(ifirst + g, h) * w) * 4u);
         };
-        issue_into(nxb, i0 + G + R, i0 + G < i1);
+        issue_into(nxb, i0 + G + R, i0 + G < i1 && bit(fetch, 1));
         // iterations in pairs; when the strip has an odd number of them the last one finds all its
         // rows past the strip and stores nothing
-        for (int ii = i0; ii < i1; ii += 2 * G) {
-            iteration(ii, 0, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1); }, SaTrue{});
-            iteration(ii + G, NBUF - 1, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1); }, SaTrue{});
+        if constexpr (!SPARSE) {
+            for (int ii = i0; ii < i1; ii += 2 * G) {
+                iteration(ii, 0, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1); }, SaTrue{}, true);
+                iteration(ii + G, NBUF - 1, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1); }, SaTrue{}, true);
+            }
+        } else {
+            // the LDS buffers alternate between evaluated iterations only: each evaluated iteration has
+            // one barrier, and a buffer is written again two evaluated iterations after it was read
+            int lb = 0, j = 0;
+            for (int ii = i0; ii < i1; ii += 2 * G, j += 2) {
+                const bool r0 = bit(need, j), r1 = bit(need, j + 1);
+                iteration(ii, lb, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1 && bit(fetch, j + 2)); }, SaTrue{}, r0);
+                if (r0) lb ^= 1;
+                iteration(ii + G, lb, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1 && bit(fetch, j + 3)); }, SaTrue{}, r1);
+                if (r1) lb ^= 1;
+            }
         }
     } else {
-        int buf = 0;
-        for (int ii = i0; ii < i1; ii += G, buf ^= (NBUF - 1)) {
+        int buf = 0, j = 0;
+        for (int ii = i0; ii < i1; ii += G, ++j) {
             finish_rows();
-            iteration(ii, buf, nx, [&] { if (ii + G < i1) issue_rows(ii + G + R); }, SaFalse{});
+            const bool run = !SPARSE || bit(need, j);
+            iteration(ii, buf, nx, [&] { if (ii + G < i1 && (!SPARSE || bit(fetch, j + 1))) issue_rows(ii + G + R); }, SaFalse{}, run);
+            if (run) buf ^= (NBUF - 1);
         }
     }
 #ifdef SA_BLUR_CLOCK
@@ -2128,7 +2190,10 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     // sequentially, so small octaves get short strips to keep enough blocks in flight
     const char* fs = getenv("SIFT_AMD_STRIP");          // forces a strip height (tests, A/B runs)
     const int forced = fs ? atoi(fs) : 0;
-    int strip = EW == 512 ? 256 : 64;
+    const bool sparse = a.need_cells && a.ovs_w == 0 && !a.dog && !a.flags && (a.w & 3) == 0;
+    // sparse launches: a block walks only from its first to its last needed group of rows, so tall
+    // strips cost no prologue where nothing is needed
+    int strip = EW == 512 ? 256 : (sparse ? 256 : 64);
     const long long cols = (a.w + TW - 1) / TW;
     while (strip > 16 && cols * ((a.h + strip - 1) / strip) * a.batch * (EW / 256) < 2048) strip >>= 1;
     if (EW == 512 && a.ovs_w == 0) {
@@ -2137,10 +2202,15 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
         // while there are too few blocks
         int n = (a.h + 256) / 512 > 0 ? (a.h + 256) / 512 : 1;
         auto rows = [&](int parts) { return (((a.h + parts - 1) / parts) + 7) & ~7; };
+        if (sparse) while (rows(n) > 512) ++n;        // one bit per 8-row group of a strip
         while (rows(n) > 16 && cols * ((a.h + rows(n) - 1) / rows(n)) * a.batch * 2 < 2048) n *= 2;
         strip = rows(n);
     }
     if (forced > 0) strip = (forced + 7) & ~7;     // the kernel relies on strips of whole 8-row groups
+    if (sparse) {
+        if (strip > 512) strip = 512;
+        ls_add(SIFT_AMD_LS_SPARSE);
+    }
     const int nbx = (int)cols, nby = (a.h + strip - 1) / strip, nblocks = nbx * nby * a.batch;
     if (EW == 512 && a.ovs_w == 0 && strip >= 64) {      // the kernel's two-iterations-ahead branch
         ls_add(SIFT_AMD_LS_WIDE_AHEAD2);
@@ -2151,9 +2221,10 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
     float* out = a.out;
     SaTapPairs tp2;
     for (int k = 0; k <= SA_MAX_RADIUS_FAST; ++k) { tp2.g[k].x = a.taps.g[k]; tp2.g[k].y = a.taps.g[k]; }
-#define SA_BLUR_LAUNCH(OVS_, VW_, PREV_, ...)                                                                \
-    HIPK((k_blur_fused<R, OVS_, EW, NBUF, VW_, PREV_>), dim3(nblocks), dim3(EW), (OVS_ || PREV_ ? 0 : pad_np), st, a.in, out, a.dog, a.sub, a.w, a.h, \
-         a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, __VA_ARGS__, a.flags, a.flag_thr)
+#define SA_BLUR_LAUNCH_S(OVS_, VW_, PREV_, SPARSE_, ...)                                                      \
+    HIPK((k_blur_fused<R, OVS_, EW, NBUF, VW_, PREV_, SPARSE_>), dim3(nblocks), dim3(EW), (OVS_ || PREV_ ? 0 : pad_np), st, a.in, out, a.dog, a.sub, a.w, a.h, \
+         a.s_in, a.s_out, a.s_dog, a.s_sub, tp2, strip, nbx, nby, nblocks, __VA_ARGS__, a.flags, a.flag_thr, a.need_cells)
+#define SA_BLUR_LAUNCH(OVS_, VW_, PREV_, ...) SA_BLUR_LAUNCH_S(OVS_, VW_, PREV_, false, __VA_ARGS__)
     const bool vw = (a.w & 3) == 0;
     const bool prev = a.dog || a.flags;
     // Occupancy (measured, 128 1080p images): the seed launch, whose loads interpolate, runs 12 % faster
@@ -2168,10 +2239,12 @@ static void blur_fused_launch(hipStream_t st, const BlurArgs& a)
         if (vw) SA_BLUR_LAUNCH(false, true, true, 0, 0, 0.f);
         else SA_BLUR_LAUNCH(false, false, true, 0, 0, 0.f);
     } else {
-        if (vw) SA_BLUR_LAUNCH(false, true, false, 0, 0, 0.f);
+        if (vw && sparse) SA_BLUR_LAUNCH_S(false, true, false, true, 0, 0, 0.f);
+        else if (vw) SA_BLUR_LAUNCH(false, true, false, 0, 0, 0.f);
         else SA_BLUR_LAUNCH(false, false, false, 0, 0, 0.f);
     }
 #undef SA_BLUR_LAUNCH
+#undef SA_BLUR_LAUNCH_S
 }
 
 template <int R>
@@ -2182,8 +2255,12 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
     // the smaller halo share and fewer idle row-pass slots (~5 % on octave 0 of a 1080p image) but
     // wastes most of a tile on narrow octaves.  SIFT_AMD_WIDE_MIN=<width> forces the choice by width.
     const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 0;
-    const bool wide = wide_min > 0 ? a.w >= wide_min
-                                   : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
+    bool wide = wide_min > 0 ? a.w >= wide_min
+                             : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
+    // launches that compute only the needed parts decide per 8-row group of a tile: narrow tiles skip more
+    // (SIFT_AMD_SPARSE_WIDE=1/0 forces wide/narrow tiles for them)
+    if (a.need_cells)
+        if (const char* m = getenv("SIFT_AMD_SPARSE_WIDE")) wide = atoi(m) != 0;
     if (wide) blur_fused_launch<R, 512, 2>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }

@@ -26,6 +26,9 @@ struct BlurArgs {
     float ovs_delta = 0.f;
     int* flags = nullptr;    // fused kernel only: marks of 8x64 cells holding a |DoG| sample > flag_thr
     float flag_thr = 0.f;
+    // fused kernel, plain launches only: marks of the cells whose neighbourhood is the only part of
+    // `out` that will be read; the rest of `out` is then left as it is (nullptr = whole image)
+    const int* need_cells = nullptr;
 };
 
 // two successive blurs of one octave in one launch (in -> out_a -> out_b)

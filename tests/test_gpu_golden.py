@@ -45,7 +45,10 @@ def test_hip_reproduces_golden(hip, name):
         std_fast, keys_fast = fast.keypoints(0)
         with pytest.raises(sift_amd.api.SiftAmdError):
             fast.scalespace(0, 1, 0)                     # DoG images are not stored on this path
-        assert digest(fast.scalespace(0, 0, n_oct - 1)) == e["gss_sha1"][n_oct - 1]
+        # (its last image of a stack is computed only where the scan and the refinement read it)
+        for o in (0, n_oct - 1):
+            stack = fast.scalespace(0, 0, o)
+            assert [digest(im) for im in stack[:-1]] == e["gss_image_sha1"][o][:-1]
     assert std_fast.tobytes() == std.tobytes() and keys_fast.tobytes() == keys.tobytes()
     ints = np.stack([keys["o"], keys["s"], keys["i"], keys["j"]], 1).astype(np.int32)
     assert digest(ints) == e["keys_sha1"]["ints"]
@@ -69,6 +72,9 @@ def test_hip_reproduces_golden(hip, name):
 # Diagnostic switches, read when a context is created.  Each selects another route through the
 # same arithmetic and must give the same bytes as the default route.
 SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
+            {"SIFT_AMD_SPARSE": "0"},     # the last image of every stack computed everywhere
+            {"SIFT_AMD_SPARSE_WIDE": "1", "SIFT_AMD_STRIP": "72"},   # ... only where needed, 480-column tiles, short strips
+            {"SIFT_AMD_SPARSE_WIDE": "0", "SIFT_AMD_STRIP": "40"},   # ... 224-column tiles
             {"SIFT_AMD_PAIR": "0"},       # every blur a launch of its own (no two-blur launches)
             {"SIFT_AMD_PAIR_STRIP": "64"},   # two-blur launches forced, in short strips
             # single-blur launches in strips of 9 iterations; on octaves that take 480-column tiles
@@ -104,8 +110,11 @@ def test_diagnostic_switches_give_the_same_records(hip, monkeypatch, name, env):
                 wide = any(((w + 479) // 480) * 512 < ((w + 223) // 224) * 256 for w, _ in ctx.dims)
                 if "SIFT_AMD_WIDE_MIN" in env:
                     wide = ctx.dims[0][0] >= 300
-                if "SIFT_AMD_STRIP" in env and wide:
+                if int(env.get("SIFT_AMD_STRIP", 0)) >= 64 and wide:
                     assert st["wide_ahead2"] > 0 and st["wide_ahead2_strip_max"] == ((int(env["SIFT_AMD_STRIP"]) + 7) & ~7), st
+                sparse_ok = any(w % 4 == 0 for w, _ in ctx.dims)       # the sparse form takes 16-byte items only
+                assert (st["sparse"] > 0) == (sparse_ok and env.get("SIFT_AMD_SPARSE") != "0"
+                                              and env.get("SIFT_AMD_CELLS") != "0"), st
                 if env.get("SIFT_AMD_PAIR") == "0":
                     assert st["pair"] == 0 and st["pair_seed"] == 0, st
                 if "SIFT_AMD_PAIR_STRIP" in env and ctx.dims[0][0] >= 900 and ctx.dims[0][0] % 4 == 0:
@@ -120,3 +129,44 @@ def test_diagnostic_switches_give_the_same_records(hip, monkeypatch, name, env):
                 assert np.array_equal(orih.view(np.uint32), g["orihist"].view(np.uint32))
         sizes, _ = ctx.stage_counts(0)
         assert sizes[1:].tolist() == [sum(e["stage_counts_per_octave"][s]) for s in "BCDEF"]
+
+
+@pytest.mark.parametrize("name,env", [("natural_800x640_a", {}), ("natural_480x270", {"SIFT_AMD_SPARSE_WIDE": "1"}),
+                                      ("smooth_800x640", {"SIFT_AMD_STRIP": "512"})])
+def test_last_stack_image_where_it_is_read(hip, monkeypatch, name, env):
+    """The batched pipeline computes the last Gaussian image of an octave only near samples that
+    pass the first contrast test.  Everything within 6 samples of an 8 x 64 cell that holds such a
+    sample (every place the scan and the refinement can read) equals the oracle's image bit for bit."""
+    from oracle import pyoracle
+    e = INDEX[name]
+    img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
+    want = pyoracle.run(img, keep_ss=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    api.launch_stats(reset=True)
+    with sift_amd.Context(e["w"], e["h"], 3) as ctx:
+        ctx.detect_host(np.stack([img, img, img]))
+        assert api.launch_stats()["sparse"] == sum(w % 4 == 0 for w, _ in ctx.dims)    # (16-byte items only)
+        thr = ctx.geometry.thresh_pre
+        checked = 0
+        for o in range(ctx.n_oct):
+            dog = want["dog"][o]
+            h, w = dog.shape[1:]
+            hit = (np.abs(dog[1:-1]) > np.float32(thr)).any(0)
+            ch, cw = (h + 7) // 8, (w + 63) // 64
+            pad = np.zeros((ch * 8, cw * 64), bool)
+            pad[:h, :w] = hit
+            cells = np.repeat(np.repeat(pad.reshape(ch, 8, cw, 64).any((1, 3)), 8, 0), 64, 1)[:h, :w]
+            near = np.zeros_like(cells)
+            ys, xs = np.nonzero(cells)
+            for dy in (-6, 0, 6):                       # cells are 8 x 64 blocks: their corners moved by 6 cover the dilation
+                for dx in (-6, 0, 6):
+                    near[np.clip(ys + dy, 0, h - 1), np.clip(xs + dx, 0, w - 1)] = True
+            for b in (0, 2):
+                got = ctx.scalespace(b, 0, o)[-1]
+                ref = want["gss"][o][-1]
+                assert np.array_equal(got.view(np.uint32)[near], ref.view(np.uint32)[near]), f"octave {o} image {b}"
+            checked += int(near.sum())
+        assert checked > 1000
+        std, _ = ctx.keypoints(1)
+    assert len(std) == e["n_keys"]

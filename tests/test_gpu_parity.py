@@ -303,12 +303,13 @@ def test_two_blur_launches_in_a_batch_equal_single_image_runs(hip):
             one.detect_host(imgs[b])
             std, keys = one.keypoints(0)
             single.append((b, std.tobytes(), keys.tobytes(),
-                           [one.scalespace(0, 0, o).tobytes() for o in range(one.n_oct)]))
+                           # (the last image of a stack is computed only where it is read: not compared)
+                           [one.scalespace(0, 0, o)[:-1].tobytes() for o in range(one.n_oct)]))
     with sift_amd.Context(w, h, max_batch=nb) as ctx:
         ctx.detect_host(imgs)
         for b, std_b, keys_b, gss in single:
             std, keys = ctx.keypoints(b)
             assert std.tobytes() == std_b and keys.tobytes() == keys_b, f"image {b}"
             for o in range(ctx.n_oct):
-                assert ctx.scalespace(b, 0, o).tobytes() == gss[o], f"image {b} octave {o}"
+                assert ctx.scalespace(b, 0, o)[:-1].tobytes() == gss[o], f"image {b} octave {o}"
     assert len(single[0][1]) > 144 * 50
