@@ -616,7 +616,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
     };
-    if (!OVS && EW == 512 && strip >= 8 * G) {
+    if (!OVS && (EW == 512 || SPARSE) && strip >= 8 * G) {
         // Source rows are fetched two iterations ahead, into two register sets used in turn.  When an
         // iteration waits for its rows, the eight loads of the following iteration are always younger
         // than them: the wait (vmcnt counts loads and stores in issue order) then never extends to
@@ -2257,10 +2257,15 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
     const int wide_min = getenv("SIFT_AMD_WIDE_MIN") ? atoi(getenv("SIFT_AMD_WIDE_MIN")) : 0;
     bool wide = wide_min > 0 ? a.w >= wide_min
                              : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
-    // launches that compute only the needed parts decide per 8-row group of a tile: narrow tiles skip more
-    // (SIFT_AMD_SPARSE_WIDE=1/0 forces wide/narrow tiles for them)
-    if (a.need_cells)
+    // Launches that compute only the needed parts decide per 8-row group of a tile, so narrow tiles skip
+    // more: on the wide octaves, where an image has regions without contrast, they are the better choice
+    // (128 natural-like 1080p images, last image of octave 0: 1.35 ms against 1.95 with wide tiles, 2.2
+    // computed everywhere; white noise, nothing to skip: 2.5 against 2.45); the small octaves are needed
+    // almost everywhere on every workload.  SIFT_AMD_SPARSE_WIDE=1/0 forces wide/narrow tiles for them.
+    if (a.need_cells) {
         if (const char* m = getenv("SIFT_AMD_SPARSE_WIDE")) wide = atoi(m) != 0;
+        else if (a.w >= 1500) wide = false;
+    }
     if (wide) blur_fused_launch<R, 512, 2>(st, a);
     else blur_fused_launch<R, 256, 2>(st, a);
 }
