@@ -681,6 +681,25 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 // symmetric and the pair sums commute).  A tile is 512 columns wide: the producer's results are
 // valid on 512 - 2 HA of them, the consumer's on 512 - 2 (HA + HB), the columns a block stores
 // (HA, HB: the radii rounded up to a multiple of 4).
+#ifdef SA_PAIR_CLOCK
+// Diagnostic build only: shader-clock ticks the waves of the two-blur launches spend per phase of an
+// iteration, summed over all waves: [OVS][role][phase], phases = rows into the window (incl. the wait
+// for their loads) / column pass / barrier / row pass and stores / iterations.
+__device__ unsigned long long sa_pair_clock[2][2][5];
+extern "C" void sift_amd_debug_pair_clock(unsigned long long* out, int reset)
+{
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(sa_pair_clock), sizeof(sa_pair_clock));
+    if (reset) { unsigned long long z[20] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(sa_pair_clock), z, sizeof(z)); }
+}
+#define SA_PC_DECL unsigned long long pc_t = __builtin_amdgcn_s_memtime(), pc_acc[5] = {0, 0, 0, 0, 0}
+#define SA_PC_MARK(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pc_acc[k] += n_ - pc_t; pc_t = n_; } while (0)
+#define SA_PC_FLUSH(ovs, role) do { if ((tid & 63) == 0) for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&sa_pair_clock[ovs][role][k_], pc_acc[k_]); } while (0)
+#else
+#define SA_PC_DECL
+#define SA_PC_MARK(k)
+#define SA_PC_FLUSH(ovs, role)
+#endif
+
 namespace pairk {
 constexpr int G = 8, EW = 512;
 struct Geo {
@@ -851,15 +870,19 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
     }
     // iteration j stores rows r0 + 8j ..., if its rows still reach the consumer before the consumer's
     // last iteration (j + 2 < n_iter); n_iter is even
+    SA_PC_DECL;
     auto iteration = [&](int j, int buf, RowSet& rs) {
         const int ii = r0 + G * j;
         const bool work = j + 2 < g.n_iter;
         take(rs);
         issue(rs, ii + 2 * G + R, j + 4 < g.n_iter);
+        SA_PC_MARK(0);
         float* tmp = l_tmp + buf * G * PITCH;
         float* prev = l_prev + (PREV ? buf * G * PITCH : 0);
         if (work) col_pass<R, PITCH, PREV>(wp, tp, tmp, prev, tid);
+        SA_PC_MARK(1);
         __syncthreads();
+        SA_PC_MARK(2);
         if (work) {
             float* slot = ring + buf * G * PITCH;
 #pragma unroll
@@ -878,6 +901,10 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
         }
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+        SA_PC_MARK(3);
+#ifdef SA_PAIR_CLOCK
+        pc_acc[4] += 1;
+#endif
     };
     RowSet ra, rb;
     issue(ra, r0 + R, true);
@@ -886,6 +913,7 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
         iteration(j, 0, ra);
         iteration(j + 1, 1, rb);
     }
+    SA_PC_FLUSH(OVS ? 1 : 0, 0);
 }
 
 template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB>
@@ -901,15 +929,19 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* 
 #pragma unroll
     for (int q = 0; q < G; ++q) nx[q] = 0.f;
     int buf = 0;
+    SA_PC_DECL;
     for (int j = 0; j < g.n_iter; ++j, buf ^= 1) {
         const int ii = r0 + G * j;
         const bool work = j >= warm;         // the window holds produced rows only from here on
 #pragma unroll
         for (int q = 0; q < G / 2; ++q) wp[R + q] = v2f{nx[2 * q], nx[2 * q + 1]};
+        SA_PC_MARK(0);
         float* tmp = l_tmp + buf * G * PITCH;
         float* prev = l_prev + (PREV ? buf * G * PITCH : 0);
         if (work) col_pass<R, PITCH, PREV>(wp, tp, tmp, prev, tid);
+        SA_PC_MARK(1);
         __syncthreads();
+        SA_PC_MARK(2);
         // the rows the producer left in its previous iteration (slot (j-1)&1)
         const float* slot = ring + ((j + 1) & 1) * G * PITCH;
 #pragma unroll
@@ -929,7 +961,12 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* 
         }
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
+        SA_PC_MARK(3);
+#ifdef SA_PAIR_CLOCK
+        pc_acc[4] += 1;
+#endif
     }
+    SA_PC_FLUSH(SUB ? 0 : (HA == 8 && HB == 8 && !PREV ? 1 : 0), 1);
 }
 }  // namespace pairk
 
