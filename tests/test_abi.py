@@ -174,3 +174,20 @@ def test_blur_kernels_have_no_fused_multiply_add(tmp_path):
     n_fused = sum("k_blur_fused" in k for k in seen)
     assert n_fused >= 64, f"only {n_fused} k_blur_fused instantiations in the disassembly"
     assert not bad, f"fused multiply-adds in bit-exact kernels: {bad}"
+
+
+def test_quotient_by_a_precomputed_reciprocal_is_the_correctly_rounded_quotient(tmp_path):
+    """div_by_uniform (sift_kernels.hip) replaces a / b by q = a*y, q + (a - b*q)*y with y = RN(1/b)
+    in the orientation and descriptor kernels.  tests/c_host/div_by_uniform_check.c runs the same
+    three operations on the CPU (fmaf / fma are exact FMAs) against '/' on adversarial mantissas, every
+    float mantissa for the denominators in use, and 8e7 random operand pairs."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "dbu")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "c_host", "div_by_uniform_check.c"), "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout
+    assert "float: 0 of" in out.stdout and "double: 0 of" in out.stdout, out.stdout
