@@ -28,7 +28,11 @@ def test_bench_line_on_small_images(hip):
     assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["value"] > 0
     assert out["repeats"]["n"] == 2 and out["config"]["keypoints_per_image"] > 10
     r = out["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and len(r["per_launch"]) == 6
+    # six blur launches of octave 0 at this batch size; the one of the last image, evaluated only where it
+    # is read, is listed apart and kept out of the roofline figure
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1
+    assert len(r["per_launch"]) == 5 and r["sparse_launch"]["scale"] == 5 and not r["sparse_launch"]["in_roofline"]
+    assert out.get("verified") is None or out["verified"]["ok"]      # (no fixture of this size)
     assert all(e["binding"] in ("hbm", "valu") for e in r["per_launch"])
 
 

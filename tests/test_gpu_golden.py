@@ -84,6 +84,9 @@ SWITCHES = [{"SIFT_AMD_CELLS": "0"},      # extrema scan without contrast marks
             {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "544"},   # the same path with tall strips, every radius
             {"SIFT_AMD_PAIR": "0", "SIFT_AMD_STRIP": "72"},
             {"SIFT_AMD_WIDE_MIN": "300", "SIFT_AMD_STRIP": "64"},   # 480-column tiles forced on every octave >= 300 wide
+            {"SIFT_AMD_FORK": "0"},       # one chain of launches (small batches alternate the octaves between two
+                                          # streams by default: parallel branches of the graph)
+            {"SIFT_AMD_FORK": "1", "SIFT_AMD_GRAPH": "0"},
             {"SIFT_AMD_GRAPH": "0"},      # no hipGraph replay
             {"SIFT_AMD_DEBUG": "1"},      # generic descriptor instantiation
             {"SIFT_AMD_DEBUG": "2"},      # descriptor contributions listed per cell instead of per bin

@@ -98,6 +98,20 @@ def test_bench_batch_4k(hip):
         check_records(recs, counts, order, [0, 1, 31])
 
 
+@pytest.mark.parametrize("fork", ["0", "1"])
+def test_bench_batch_both_schedules(hip, monkeypatch, fork):
+    """The benchmark's batch as one chain of launches and as two interleaved chains (the default for
+    small batches only): same records."""
+    monkeypatch.setenv("SIFT_AMD_FORK", fork)
+    names = ["natural_1920x1080", "smooth_1920x1080", "white_1920x1080"]
+    batch, order = golden_batch(names, 48)
+    with sift_amd.Context(1920, 1080, 48) as ctx:
+        for _ in range(3):
+            ctx.detect_host(batch)
+            recs, counts = ctx.gather()
+            check_records(recs, counts, order, [0, 1, 2, 45, 46, 47])
+
+
 @pytest.mark.parametrize("name", ["white_480x270", "natural_480x270"])
 def test_wide_tiles_default_strips(hip, name):
     """Octaves 960 and 480 wide pick the 480-column tiles; a batch of 256 gives them their default
