@@ -5,8 +5,9 @@ set -e
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-# octave-0 blur launch of 128 1080p images (the bench's batch): 8 x 4 tiles of 480 x 544 outputs
-# per image, 512 threads
+# octave-0 blur launch of 128 1080p images (the bench's batch) that evaluates every pixel (R = 10): 8 x 4 tiles
+# of 480 x 544 outputs per image, 512 threads (the launch of the last image, evaluated only where it is read,
+# has another grid and stays out of the dominant group)
 BATCH=128
 DOM_BLOCKS=$((8 * 4 * BATCH))
 DOM_THREADS=512
@@ -31,6 +32,7 @@ timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout -k 10 300 python3 bench.py --no-cpu --no-extras --pipeline 1 > $OUT/bench_pipeline1.json 2>> $OUT/bench.err
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 128 --roofline > $OUT/per_kernel_roofline_b128.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 128 --kind white > $OUT/per_kernel_white_b128.md 2>&1
+timeout -k 10 200 python3 tools/kernel_bench.py --batch 128 --kind natural > $OUT/per_kernel_natural_b128.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 > $OUT/per_kernel_single_1080p.md 2>&1
 timeout -k 10 200 python3 tools/kernel_bench.py --batch 1 --w 3840 --h 2160 > $OUT/per_kernel_single_4k.md 2>&1
 # what the hardware gives: copy ceiling of HBM, issue rate of packed against plain f32 instructions
