@@ -3,7 +3,7 @@
 The blur launches depend on the batch: large batches of wide octaves take the two-blur launches
 with 1080-row strips and the single-blur launches that fetch rows two iterations ahead in strips
 of ~544 rows, which a batch of one never reaches.  These tests run the full-size golden images
-inside batches of the benchmark's size (128 images of 1920x1080, 32 of 3840x2160) and compare the
+inside batches of the benchmark's size (320 images of 1920x1080, 64 of 3840x2160) and compare the
 records and the Gaussian stacks of several slots with the fixtures the compiled reference produced;
 the launch-route counters of the library show that the routes meant were the ones taken."""
 import numpy as np
@@ -54,9 +54,10 @@ def check_stacks(ctx, order, slots, sparse_last):
 
 
 def test_bench_batch_1080p(hip):
-    """128 images of 1920x1080: the benchmark's launch geometry."""
+    """320 images of 1920x1080: the benchmark's batch and launch geometry (the launch shapes are the
+    same from 128 images on: every launch has more blocks than the thresholds that shorten strips)."""
     names = ["smooth_1920x1080", "white_1920x1080", "natural_1920x1080"]
-    B = 128
+    B = 320
     batch, order = golden_batch(names, B)
     api.launch_stats(reset=True)
     with sift_amd.Context(1920, 1080, B) as ctx:
@@ -67,12 +68,16 @@ def test_bench_batch_1080p(hip):
         # the radius-10/13 launches of the wide octaves fetch rows two iterations ahead
         assert st["pair_seed"] == 1 and st["pair"] >= 2 and st["pair_strip_max"] == 1080, st
         assert st["wide_ahead2"] >= 4 and st["wide_ahead2_strip_max"] >= 544, st
-        check_records(recs, counts, order, [0, 1, 2, 63, 64, 65, 125, 126, 127])
-        check_stacks(ctx, order, [0, 1, 2, 127], sparse_last=st["sparse"] > 0)
+        check_records(recs, counts, order, [0, 1, 2, 127, 128, 129, 160, 317, 318, 319])
+        check_stacks(ctx, order, [0, 1, 2, 319], sparse_last=st["sparse"] > 0)
         for _ in range(2):                         # hipGraph build, replay
             ctx.detect_host(batch)
             recs, counts = ctx.gather()
-            check_records(recs, counts, order, [0, 1, 2, 127])
+            check_records(recs, counts, order, [0, 1, 2, 319])
+        # 128 images (the batch of earlier measurements) through the same context
+        ctx.detect_host(batch[:128])
+        recs, counts = ctx.gather()
+        check_records(recs, counts, order[:128], [0, 1, 2, 63, 64, 65, 125, 126, 127])
         # a partial batch through the same context
         ctx.detect_host(batch[:37])
         recs, counts = ctx.gather()
@@ -80,9 +85,9 @@ def test_bench_batch_1080p(hip):
 
 
 def test_bench_batch_4k(hip):
-    """32 images of 3840x2160, the benchmark's 4K leg."""
+    """64 images of 3840x2160, the benchmark's 4K leg."""
     names = ["smooth_3840x2160", "white_3840x2160"]
-    B = 32
+    B = 64
     batch, order = golden_batch(names, B)
     api.launch_stats(reset=True)
     with sift_amd.Context(3840, 2160, B) as ctx:
@@ -90,12 +95,12 @@ def test_bench_batch_4k(hip):
         recs, counts = ctx.gather()
         st = api.launch_stats(reset=True)
         assert st["pair_seed"] == 1 and st["pair"] >= 2 and st["wide_ahead2"] >= 4, st
-        check_records(recs, counts, order, [0, 1, 30, 31])
-        check_stacks(ctx, order, [0, 31], sparse_last=st["sparse"] > 0)
+        check_records(recs, counts, order, [0, 1, 30, 31, 62, 63])
+        check_stacks(ctx, order, [0, 63], sparse_last=st["sparse"] > 0)
         ctx.detect_host(batch)
         ctx.detect_host(batch)
         recs, counts = ctx.gather()
-        check_records(recs, counts, order, [0, 1, 31])
+        check_records(recs, counts, order, [0, 1, 63])
 
 
 @pytest.mark.parametrize("fork", ["0", "1"])

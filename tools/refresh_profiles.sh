@@ -5,10 +5,10 @@ set -e
 TAG=${1:-rXX}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
-# octave-0 blur launch of 128 1080p images (the bench's batch) that evaluates every pixel (R = 10): 8 x 4 tiles
+# octave-0 blur launch of the bench's batch of 1080p images that evaluates every pixel (R = 10): 8 x 4 tiles
 # of 480 x 544 outputs per image, 512 threads (the launch of the last image, evaluated only where it is read,
 # has another grid and stays out of the dominant group)
-BATCH=128
+BATCH=320          # bench.py's default number of images per launch
 DOM_BLOCKS=$((8 * 4 * BATCH))
 DOM_THREADS=512
 # the radius-5/7 pair of octave 0 as one launch: 8 x 2 tiles of 480 x 1080 outputs per image, 1024 threads
