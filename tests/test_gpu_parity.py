@@ -313,3 +313,66 @@ def test_two_blur_launches_in_a_batch_equal_single_image_runs(hip):
             for o in range(ctx.n_oct):
                 assert ctx.scalespace(b, 0, o)[:-1].tobytes() == gss[o], f"image {b} octave {o}"
     assert len(single[0][1]) > 144 * 50
+
+
+def test_scale_space_only_and_whole_pipeline_runs_alternate_on_one_context(hip):
+    """A throughput context computes the last image of every stack only where it is read when it runs
+    the whole pipeline, and everywhere when only the scale-space is asked for: alternating the two
+    kinds of run (each has its own cached hipGraph) gives the complete stack after one and the
+    reference's records after the other, every time."""
+    from test_zz_no_alloc import Hip
+    from test_oracle_golden import INDEX, digest
+    name = "natural_480x270"
+    e = INDEX[name]
+    img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
+    want = pyoracle.run(img, keep_ss=False)
+    hipm = Hip()
+    d_img = hipm.upload(np.stack([img, img, img]))
+    with sift_amd.Context(e["w"], e["h"], max_batch=3) as ctx:
+        for rep in range(4):
+            ctx.scalespace_device(d_img, 3, None)
+            for o in (0, 1, ctx.n_oct - 1):
+                assert [digest(im) for im in ctx.scalespace(2, 0, o)] == e["gss_image_sha1"][o], f"run {rep} octave {o}"
+            ctx.detect_device(d_img, 3, None)
+            std, _ = ctx.keypoints(1)
+            assert len(std) == e["n_keys"]
+            assert np.array_equal(std["descriptor"], want["keys"]["descr"].astype(np.uint8))
+    hipm.free_all()
+
+
+def test_stored_dog_stacks_of_a_batch(hip):
+    """Contexts that keep the DoG stacks (and list every extremum) compute every image everywhere, also in a
+    batch small enough for the two-chain schedule: all images of the batch carry the fixture's stacks."""
+    from test_oracle_golden import INDEX, digest
+    name = "white_480x270"
+    e = INDEX[name]
+    img = synth.make(e["kind"], e["w"], e["h"], e["seed"])
+    with sift_amd.Context(e["w"], e["h"], 4, keep_all_extrema=True, keep_scalespace=True) as ctx:
+        for _ in range(3):
+            ctx.detect_host(np.stack([img] * 4))
+            for b in (0, 3):
+                for o in range(ctx.n_oct):
+                    assert digest(ctx.scalespace(b, 0, o)) == e["gss_sha1"][o]
+                    assert digest(ctx.scalespace(b, 1, o)) == e["dog_sha1"][o]
+                sizes, ext = ctx.stage_counts(b)
+                assert ext.tolist() == e["stage_counts_per_octave"]["A"]
+                assert len(ctx.keypoints(b)[0]) == e["n_keys"]
+
+
+def test_eight_bit_input_through_both_schedules(hip, monkeypatch):
+    """8-bit images converted on the GPU, then the pipeline as one chain and as two chains: the records of
+    the float path on the same values."""
+    rng = np.random.default_rng(5)
+    w, h = 320, 200
+    u8 = rng.integers(0, 256, (2, h, w), dtype=np.uint8)
+    f32 = (u8.astype(np.float32).astype(np.float64) / 256.0).astype(np.float32)
+    with sift_amd.Context(w, h, max_batch=2) as ref:
+        ref.detect_host(f32)
+        want = [ref.keypoints(b)[0].tobytes() for b in range(2)]
+    assert len(want[0]) > 144 * 100
+    for fork in ("0", "1"):
+        monkeypatch.setenv("SIFT_AMD_FORK", fork)
+        with sift_amd.Context(w, h, max_batch=2) as ctx:
+            for _ in range(3):
+                ctx.detect_host_u8(u8)
+                assert [ctx.keypoints(b)[0].tobytes() for b in range(2)] == want
