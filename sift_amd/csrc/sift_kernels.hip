@@ -42,6 +42,10 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned lane_
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane_bytes, row_bytes, 0));
 }
+__device__ __forceinline__ v2f buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, lane_bytes, row_bytes, 0));
+}
 __device__ __forceinline__ void buf_st1(__amdgpu_buffer_rsrc_t r, unsigned lane_bytes, unsigned row_bytes, float v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, lane_bytes, row_bytes, 0);
@@ -767,7 +771,10 @@ __device__ __forceinline__ void emit(const Geo& g, __amdgpu_buffer_rsrc_t r_out,
         buf_st2(r_sub, (unsigned)((row >> 1) * (g.w >> 1) + (xo >> 1)) * 4u, 0u, v2f{o4[0], o4[2]});
 }
 
-template <int R, int HA, int HB, int PITCH, bool PREV, bool OVS>
+// CSA: the consumer writes the producer's image to memory (from the ring slot it reads anyway), so
+// that the producer issues loads only: its wait for a set of rows never includes a store, and the
+// role with the spare time does the storing.
+template <int R, int HA, int HB, int PITCH, bool PREV, bool OVS, bool CSA, bool ODD>
 __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, float delta, float* out_img, int* flags_img,
                                          const SaTapPairs& tp, float flag_thr, const Geo& g, int r0, int tid,
                                          float* l_tmp, float* l_prev, float* ring)
@@ -799,19 +806,24 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
     // same two input rows: their horizontally interpolated rows are loaded once (raw samples issued
     // by issue(), interpolation in take() two iterations later); rows that need mirroring take the
     // per-sample path (same expressions as k_blur_fused).
-    struct RowSet { float nx[G]; float raw[OVS ? 2 * (G / 2 + 2) : 1]; bool pending, odd; };
-    const bool half_step = OVS && delta == 0.5f;
+    // The parity of the first row of a set is that of RA + RB (strips start at multiples of 8 rows): 8 rows of
+    // an even start interpolate 5 input rows, of an odd start 6.  A thread's two input columns are neighbours
+    // in memory (jp = jm + 1; in the last column both are the last sample), so one 8-byte load fetches both.
+    constexpr int NROWS = G / 2 + 1 + (ODD ? 1 : 0);
+    struct RowSet { float nx[G]; v2f raw[OVS ? NROWS : 1]; bool pending; };
+    const bool half_step = OVS && delta == 0.5f && wi >= 2;
+    const bool last_col = OVS && oc.jp != oc.jm + 1;
+    const unsigned jm2 = OVS ? (unsigned)min(oc.jm, wi - 2) * 4u : 0u;
     auto issue = [&](RowSet& rs, int ifirst, bool live) {
-        const bool shared = OVS && half_step && ifirst >= 0 && ifirst + G - 1 < g.h && ((ifirst + G - 1) >> 1) + 1 < hi;
+        const bool shared = OVS && half_step && (ifirst & 1) == (ODD ? 1 : 0) && ifirst >= 0 && ifirst + G - 1 < g.h &&
+                            ((ifirst + G - 1) >> 1) + 1 < hi;
         if (OVS && (shared || !live)) {
             const int m = shared ? ifirst >> 1 : 0;
-            rs.odd = ifirst & 1;
-            const unsigned jp = live ? oc.jp * 4u : OOB, jm = live ? oc.jm * 4u : OOB;
+            const unsigned jpair = live ? jm2 : OOB;
 #pragma unroll
-            for (int t = 0; t < G / 2 + 2; ++t) {
+            for (int t = 0; t < NROWS; ++t) {
                 const unsigned rp = (unsigned)(min(m + t, hi - 1) * wi) * 4u;
-                rs.raw[OVS ? 2 * t : 0] = buf_ld(src, jp, rp);
-                rs.raw[OVS ? 2 * t + 1 : 0] = buf_ld(src, jm, rp);
+                rs.raw[OVS ? t : 0] = buf_ld2(src, jpair, rp);
             }
             rs.pending = true;
         } else if (OVS) {
@@ -828,13 +840,16 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
     // the set's rows into the top of the column window
     auto take = [&](RowSet& rs) {
         if (OVS && rs.pending) {
-            float H[G / 2 + 2];
+            float H[NROWS];
 #pragma unroll
-            for (int t = 0; t < G / 2 + 2; ++t)
-                H[t] = __fadd_rn(__fmul_rn(oc.fy, rs.raw[OVS ? 2 * t : 0]), __fmul_rn(1 - oc.fy, rs.raw[OVS ? 2 * t + 1 : 0]));
+            for (int t = 0; t < NROWS; ++t) {
+                const v2f in2 = rs.raw[OVS ? t : 0];          // samples jm2, jm2 + 1 of the row
+                const float a = in2.y, b = last_col ? in2.y : in2.x;
+                H[t] = __fadd_rn(__fmul_rn(oc.fy, a), __fmul_rn(1 - oc.fy, b));
+            }
             // row ifirst + q: input rows (ifirst + q) / 2 and the next one, weight 1/2 on odd rows
             float v[G];
-            if (rs.odd) {
+            if (ODD) {
 #pragma unroll
                 for (int q = 0; q < G; ++q) {
                     const int t = (q + 1) >> 1;
@@ -894,7 +909,7 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
                     row_item<R, HA>(tmp + hg * PITCH + 4 * hq, tp, o4);
                     const int cg = HA + 4 * hq, row = ii + hg, xo = g.X0 + cg;
                     *reinterpret_cast<v4f*>(slot + hg * PITCH + cg) = v4f{o4[0], o4[1], o4[2], o4[3]};
-                    if (row >= g.i0 && row < g.i1 && xo >= g.keep_lo && xo < g.keep_hi)
+                    if (!CSA && row >= g.i0 && row < g.i1 && xo >= g.keep_lo && xo < g.keep_hi)
                         emit<PREV, false>(g, r_out, r_flags, r_out, o4, prev + (PREV ? hg * PITCH + cg : 0), flag_thr, row, xo);
                 }
             }
@@ -916,10 +931,12 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
     SA_PC_FLUSH(OVS ? 1 : 0, 0);
 }
 
-template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB>
+template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB, bool CSA>
 __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* sub_img, const SaTapPairs& tp, float flag_thr,
-                                         const Geo& g, int r0, int warm, int tid, float* l_tmp, float* l_prev, float* ring)
+                                         const Geo& g, int r0, int warm, int tid, float* l_tmp, float* l_prev, float* ring,
+                                         float* out_a_img, int r0a)
 {
+    const __amdgpu_buffer_rsrc_t r_out_a = buf_rsrc(out_a_img);
     constexpr int OFF = HA + HB, NG = (EW - 2 * OFF) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
     const __amdgpu_buffer_rsrc_t r_out = buf_rsrc(out_img), r_flags = buf_rsrc(flags_img), r_sub = buf_rsrc(sub_img);
     v2f wp[NP];
@@ -946,6 +963,19 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* 
         const float* slot = ring + ((j + 1) & 1) * G * PITCH;
 #pragma unroll
         for (int q = 0; q < G; ++q) nx[q] = slot[q * PITCH + tid];
+        if (CSA && j >= 1 && j + 1 < g.n_iter) {
+            // the slot holds rows r0a + 8 (j-1) ... of the producer's image, columns HA .. EW - HA of the tile
+            constexpr int NGA = (EW - 2 * HA) / 4, ITEMS_A = G * NGA;
+            const int ra = r0a + G * (j - 1);
+#pragma unroll
+            for (int rnd = 0; rnd < (ITEMS_A + EW - 1) / EW; ++rnd) {
+                const int item = rnd * EW + tid;
+                const int hg = item / NGA, hq = item - hg * NGA;
+                const int cg = HA + 4 * hq, row = ra + hg, xo = g.X0 + cg;
+                if (item < ITEMS_A && row >= g.i0 && row < g.i1 && xo >= g.keep_lo && xo < g.keep_hi)
+                    buf_st4(r_out_a, (unsigned)(row * g.w + xo) * 4u, 0u, ld4(slot + hg * PITCH + cg));
+            }
+        }
         if (work) {
 #pragma unroll
             for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
@@ -1001,12 +1031,15 @@ k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __re
     g.n_iter = (warm + (g.i1 - g.i0 + G - 1) / G + 1) & ~1;     // even: the producer walks its iterations in pairs
     const int r0b = g.i0 - G * warm, r0a = r0b + RB + 16;
     int* flags_img = flags ? flags + b * ((h + 7) >> 3) * (long long)g.cells_w : nullptr;
+    // seed + first blur: the producer (loads, interpolation) is the slower role, so the consumer stores
+    // both images (128 1080p images: 2.63 -> 2.51 ms; in the other pairs the consumer is the slower role)
+    constexpr bool CSA = OVS && !FA;
     if (role == 0)
-        producer<RA, HA, HB, PITCH, FA, OVS>(in + b * s_in, wi, hi, delta, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a,
-                                             tid, l_tmp[0], l_prev_a, ring);
+        producer<RA, HA, HB, PITCH, FA, OVS, CSA, ((RA + RB) & 1) != 0>(in + b * s_in, wi, hi, delta, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a,
+                                                  tid, l_tmp[0], l_prev_a, ring);
     else
-        consumer<RB, HA, HB, PITCH, FB, SUB>(out_b + b * s_b, flags_img, SUB ? sub + b * s_sub : nullptr, tp_b, flag_thr, g, r0b,
-                                             warm, tid, l_tmp[1], l_prev_b, ring);
+        consumer<RB, HA, HB, PITCH, FB, SUB, CSA>(out_b + b * s_b, flags_img, SUB ? sub + b * s_sub : nullptr, tp_b, flag_thr, g, r0b,
+                                                  warm, tid, l_tmp[1], l_prev_b, ring, out_a + b * s_a, r0a);
 }
 
 // Any radius (taps in global memory); one thread per output sample.  Only used for
