@@ -704,6 +704,9 @@ extern "C" void sift_amd_debug_pair_clock(unsigned long long* out, int reset)
 #define SA_PC_FLUSH(ovs, role)
 #endif
 
+#ifndef SA_PAIR_HELP_FROM
+#define SA_PAIR_HELP_FROM 768
+#endif
 namespace pairk {
 constexpr int G = 8, EW = 512;
 struct Geo {
@@ -774,10 +777,15 @@ __device__ __forceinline__ void emit(const Geo& g, __amdgpu_buffer_rsrc_t r_out,
 // CSA: the consumer writes the producer's image to memory (from the ring slot it reads anyway), so
 // that the producer issues loads only: its wait for a set of rows never includes a store, and the
 // role with the spare time does the storing.
-template <int R, int HA, int HB, int PITCH, bool PREV, bool OVS, bool CSA, bool ODD>
+// HELP_FROM: the consumer's row-pass items from this index on are computed by the producer's threads
+// after their own (the consumer's column-pass rows lie in LDS for everybody); it balances the two
+// roles where the consumer is the slower one.  G * NG of the consumer and more: no help.
+template <int R, int HA, int HB, int PITCH, bool PREV, bool OVS, bool CSA, bool ODD, int RB, bool FB, bool SUB, int HELP_FROM>
 __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, float delta, float* out_img, int* flags_img,
                                          const SaTapPairs& tp, float flag_thr, const Geo& g, int r0, int tid,
-                                         float* l_tmp, float* l_prev, float* ring)
+                                         float* l_tmp, float* l_prev, float* ring,
+                                         float* out_b_img, float* sub_img, const SaTapPairs& tp_b, int r0b, int warm,
+                                         float* l_tmp_c, float* l_prev_c)
 {
     constexpr int NG = (EW - 2 * HA) / 4, ITEMS = G * NG, NP = (G + 2 * R) / 2;
     constexpr unsigned OOB = 0x80000000u;       // lane offset past the descriptor's range: the access is dropped
@@ -914,6 +922,21 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
                 }
             }
         }
+        constexpr int OFF_C = HA + HB, NG_C = (EW - 2 * OFF_C) / 4, ITEMS_C = G * NG_C;
+        if (HELP_FROM < ITEMS_C && j >= warm) {
+            static_assert(HELP_FROM >= ITEMS_C || ITEMS_C - HELP_FROM <= EW, "one helper item per thread");
+            const float* tmp_c = l_tmp_c + buf * G * PITCH;
+            const float* prev_c = l_prev_c + (FB ? buf * G * PITCH : 0);
+            const int item = HELP_FROM + tid;
+            const int hg = item / NG_C, hq = item - hg * NG_C;
+            const int cg = OFF_C + 4 * hq, row = r0b + G * j + hg, xo = g.X0 + cg;
+            if (item < ITEMS_C && row < g.i1 && xo < g.keep_hi) {
+                const __amdgpu_buffer_rsrc_t r_out_b = buf_rsrc(out_b_img), r_sub = buf_rsrc(sub_img);
+                float o4[4];
+                row_item<RB, HB>(tmp_c + hg * PITCH + cg - HB, tp_b, o4);
+                emit<FB, SUB>(g, r_out_b, r_flags, r_sub, o4, prev_c + (FB ? hg * PITCH + cg : 0), flag_thr, row, xo);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < R; ++t) wp[t] = wp[t + G / 2];
         SA_PC_MARK(3);
@@ -931,7 +954,7 @@ __device__ __forceinline__ void producer(const float* in_img, int wi, int hi, fl
     SA_PC_FLUSH(OVS ? 1 : 0, 0);
 }
 
-template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB, bool CSA>
+template <int R, int HA, int HB, int PITCH, bool PREV, bool SUB, bool CSA, int HELP_FROM>
 __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* sub_img, const SaTapPairs& tp, float flag_thr,
                                          const Geo& g, int r0, int warm, int tid, float* l_tmp, float* l_prev, float* ring,
                                          float* out_a_img, int r0a)
@@ -982,7 +1005,7 @@ __device__ __forceinline__ void consumer(float* out_img, int* flags_img, float* 
                 const int item = rnd * EW + tid;
                 const int hg = item / NG, hq = item - hg * NG;
                 const int cg = OFF + 4 * hq, row = ii + hg, xo = g.X0 + cg;
-                if (item < ITEMS && row < g.i1 && xo < g.keep_hi) {
+                if (item < (HELP_FROM < ITEMS ? HELP_FROM : ITEMS) && row < g.i1 && xo < g.keep_hi) {
                     float o4[4];
                     row_item<R, HB>(tmp + hg * PITCH + cg - HB, tp, o4);
                     emit<PREV, SUB>(g, r_out, r_flags, r_sub, o4, prev + (PREV ? hg * PITCH + cg : 0), flag_thr, row, xo);
@@ -1034,11 +1057,17 @@ k_blur_pair(const float* __restrict__ in, float* __restrict__ out_a, float* __re
     // seed + first blur: the producer (loads, interpolation) is the slower role, so the consumer stores
     // both images (128 1080p images: 2.63 -> 2.51 ms; in the other pairs the consumer is the slower role)
     constexpr bool CSA = OVS && !FA;
+    // the other pairs: the consumer (larger radius, marks, next octave's seed) is the slower role, and the
+    // producer's threads take the tail of its row-pass items
+    constexpr int ITEMS_C = G * (EW - 2 * (HA + HB)) / 4;
+    constexpr int HELP_FROM = OVS ? ITEMS_C : SA_PAIR_HELP_FROM;
+    float* sub_img = SUB ? sub + b * s_sub : nullptr;
     if (role == 0)
-        producer<RA, HA, HB, PITCH, FA, OVS, CSA, ((RA + RB) & 1) != 0>(in + b * s_in, wi, hi, delta, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a,
-                                                  tid, l_tmp[0], l_prev_a, ring);
+        producer<RA, HA, HB, PITCH, FA, OVS, CSA, ((RA + RB) & 1) != 0, RB, FB, SUB, HELP_FROM>(
+            in + b * s_in, wi, hi, delta, out_a + b * s_a, flags_img, tp_a, flag_thr, g, r0a, tid, l_tmp[0], l_prev_a, ring,
+            out_b + b * s_b, sub_img, tp_b, r0b, warm, l_tmp[1], l_prev_b);
     else
-        consumer<RB, HA, HB, PITCH, FB, SUB, CSA>(out_b + b * s_b, flags_img, SUB ? sub + b * s_sub : nullptr, tp_b, flag_thr, g, r0b,
+        consumer<RB, HA, HB, PITCH, FB, SUB, CSA, HELP_FROM>(out_b + b * s_b, flags_img, sub_img, tp_b, flag_thr, g, r0b,
                                                   warm, tid, l_tmp[1], l_prev_b, ring, out_a + b * s_a, r0a);
 }
 
