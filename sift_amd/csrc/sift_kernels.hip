@@ -309,7 +309,9 @@ extern "C" void sift_amd_debug_blur_clock(unsigned long long* out, int reset)
 // neighbour is 1 sample away, a refined position at most 4 moves plus one tap, so at most 6), and
 // the marks of the 8 x 64 cells holding such samples (`need_cells`) are complete before this launch
 // starts.  A block evaluates an 8-row group of its tile only if a cell within 6 samples of it is
-// marked; the other rows of `out` keep whatever they held.  Strips have at most 64 groups.
+// marked, and within such a group only the 64-column chunks with such a cell (a wave of the row pass
+// owns a chunk x 4 rows, a wave of the column pass skips its 64 columns when no evaluated chunk reads
+// them); the other samples of `out` keep whatever they held.  Strips have at most 64 groups.
 template <int R, bool OVS, int EW, int NBUF, bool VW, bool PREV, bool SPARSE = false>
 __global__ void __launch_bounds__(EW)
 k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dog,
@@ -358,10 +360,21 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
     int i1 = min(i0 + strip, h);
     // SPARSE: bit j of `need` = the j-th 8-row group of the strip is evaluated; bit j of `fetch` = the
     // source rows that enter the column window in iteration j are used by an evaluated group
-    unsigned long long need = ~0ull, fetch = ~0ull;
+    unsigned long long need = ~0ull;
+    // SPARSE, per wave: `cneed` = groups whose column pass this wave runs (its 64 columns feed an evaluated
+    // 64-column chunk of outputs), `cfetch` = iterations whose source rows it loads, `rneed[r]` = groups in
+    // which the chunk of outputs of its round r is evaluated.  A wave of the row pass owns 64 columns x 4 rows,
+    // so everything a wave skips is skipped by all its lanes.
+    constexpr int NWV = EW / 64, NCH = (NG + 15) / 16, RROUNDS = (2 * NCH + NWV - 1) / NWV;
+    unsigned long long cneed = ~0ull, cfetch = ~0ull, rneed[RROUNDS];
+#pragma unroll
+    for (int r = 0; r < RROUNDS; ++r) rneed[r] = ~0ull;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (SPARSE) {
-        __shared__ unsigned long long l_need;
-        if (tid == 0) l_need = 0;
+        constexpr int NCC = (TW + 12 + 63) / 64 + 1;       // cell columns within 6 samples of a tile, at most
+        static_assert((NCH & (NCH - 1)) == 0 && RROUNDS == (ITEMS + EW - 1) / EW, "chunk layout");
+        __shared__ unsigned long long l_need_c[NCC];
+        if (tid < NCC) l_need_c[tid] = 0;
         __syncthreads();
         const int cw = (w + 63) >> 6, ch = (h + 7) >> 3;
         const int* cells = need_cells + b * (long long)ch * cw;
@@ -375,22 +388,43 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             if (cr >= 0 && cr < ch && cells[cr * cw + c0 + cc]) {
                 // a marked cell row needs its own group of rows and the two next to it: groups gr-2 .. gr of the strip
                 const unsigned long long m = (gr >= 2 ? 7ull << (gr - 2) : 7ull >> (2 - gr)) & strip_mask;
-                if (m) atomicOr(&l_need, m);
+                if (m) atomicOr(&l_need_c[cc], m);
             }
         }
         __syncthreads();
-        const unsigned long long nd = l_need;
-        need = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(nd >> 32)) << 32) |
-               __builtin_amdgcn_readfirstlane((unsigned)nd);
+        // groups in which output columns lo..hi are evaluated: those of the cells within 6 samples of them
+        auto cols_need = [&](int lo, int hi) -> unsigned long long {
+            unsigned long long m = 0;
+            if (lo <= hi)
+                for (int cc = max((lo - 6) >> 6, c0); cc <= min((hi + 6) >> 6, c1); ++cc) m |= l_need_c[cc - c0];
+            return ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(m >> 32)) << 32) |
+                   __builtin_amdgcn_readfirstlane((unsigned)m);
+        };
+        auto chunk_need = [&](int c) -> unsigned long long {   // chunk c: output columns x0 + 64 c ... of the tile
+            if (c < 0 || c >= NCH) return 0ull;
+            return cols_need(x0 + 64 * c, min(min(x0 + 64 * c + 63, x0 + TW - 1), w - 1));
+        };
+        need = cols_need(x0, min(x0 + TW, w) - 1);
         if (need == 0) return;
+        // column wv of the tile's LDS rows (64 samples, starting RP left of the outputs) is read by the
+        // row pass of chunks wv - 1 and wv (R <= RP = 16)
+        cneed = chunk_need(wv - 1) | chunk_need(wv);
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r) {
+            const int wr = r * NWV + wv;
+            rneed[r] = wr < 2 * NCH ? chunk_need(wr & (NCH - 1)) : 0ull;
+        }
         // the strip shrinks to the span between its first and last needed group
         const int lead = __builtin_ctzll(need);
         i0 += 8 * lead;
         need >>= lead;
-        i1 = min(i1, i0 + 8 * (64 - __builtin_clzll(need)));
-        fetch = need;
+        cneed >>= lead;
 #pragma unroll
-        for (int k = 1; k <= (2 * R + 7) / 8; ++k) fetch |= need >> k;
+        for (int r = 0; r < RROUNDS; ++r) rneed[r] >>= lead;
+        i1 = min(i1, i0 + 8 * (64 - __builtin_clzll(need)));
+        cfetch = cneed;
+#pragma unroll
+        for (int k = 1; k <= (2 * R + 7) / 8; ++k) cfetch |= cneed >> k;
     }
     auto bit = [](unsigned long long m, int j) { return j < 64 && ((m >> j) & 1ull); };
     // VW: the launcher guarantees w % 4 == 0, every 4-sample item is then a whole 16-byte access
@@ -505,7 +539,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 
     // One iteration: 8 rows of the strip starting at row ii.  nxr holds their newest source rows,
     // prefetch() starts the loads of a later iteration once nxr has been taken into the window.
-    auto iteration = [&](int ii, int buf, float (&nxr)[G], auto&& prefetch, auto pinned, bool run) {
+    auto iteration = [&](int ii, int buf, float (&nxr)[G], auto&& prefetch, auto pinned, bool run, int j) {
         if constexpr (decltype(pinned)::value) {
             // asm moves: the copies out of the load registers stay here, where only these rows' loads
             // have to be complete, instead of becoming register copies at the loop's back edge
@@ -522,6 +556,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         if (!SPARSE || run) {
         // two output pairs at a time: the two accumulation chains are independent, so a wave has a
         // second instruction to issue while the first one's result is on its way
+        if (!SPARSE || bit(cneed, j)) {
 #pragma unroll
         for (int g = 0; g < G; g += 4) {
             const v2f ctr0 = win_pair(wp, g + R), ctr1 = win_pair(wp, g + 2 + R);
@@ -545,13 +580,25 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
                 l_prev[buf][g + 3][tid] = ctr1.y;
             }
         }
+        }
         __syncthreads();
 #pragma unroll
         for (int rnd = 0; rnd < (ITEMS + EW - 1) / EW; ++rnd) {
-            const int item = rnd * EW + tid;
-            const int hg = item / NG, hq = item - hg * NG;
+            int hg, hq;
+            bool item_ok;
+            if constexpr (SPARSE) {
+                // a wave = one 64-column chunk x 4 rows (16 lanes per row)
+                const int wr = rnd * NWV + wv;
+                hg = 4 * (wr / NCH) + ((tid & 63) >> 4);
+                hq = 16 * (wr & (NCH - 1)) + (tid & 15);
+                item_ok = wr < 2 * NCH && hq < NG && bit(rneed[rnd], j);
+            } else {
+                const int item = rnd * EW + tid;
+                hg = item / NG; hq = item - hg * NG;
+                item_ok = item < ITEMS;
+            }
             const int row = ii + hg, xo = x0 + 4 * hq;
-            if (item < ITEMS && row < i1 && xo < w) {
+            if (item_ok && row < i1 && xo < w) {
                 // window as aligned pairs hp[i] = {row[2i], row[2i+1]}
                 v2f hp[(4 + 2 * RP) / 2];
                 const float* lrow = &l_tmp[buf][hg][4 * hq];
@@ -634,13 +681,13 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
 #pragma unroll
             for (int g = 0; g < G; ++g) dst[g] = buf_ld(src, lane, (unsigned)(mirror_idx(ifirst + g, h) * w) * 4u);
         };
-        issue_into(nxb, i0 + G + R, i0 + G < i1 && bit(fetch, 1));
+        issue_into(nxb, i0 + G + R, i0 + G < i1 && bit(cfetch, 1));
         // iterations in pairs; when the strip has an odd number of them the last one finds all its
         // rows past the strip and stores nothing
         if constexpr (!SPARSE) {
             for (int ii = i0; ii < i1; ii += 2 * G) {
-                iteration(ii, 0, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1); }, SaTrue{}, true);
-                iteration(ii + G, NBUF - 1, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1); }, SaTrue{}, true);
+                iteration(ii, 0, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1); }, SaTrue{}, true, 0);
+                iteration(ii + G, NBUF - 1, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1); }, SaTrue{}, true, 0);
             }
         } else {
             // the LDS buffers alternate between evaluated iterations only: each evaluated iteration has
@@ -648,9 +695,9 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
             int lb = 0, j = 0;
             for (int ii = i0; ii < i1; ii += 2 * G, j += 2) {
                 const bool r0 = bit(need, j), r1 = bit(need, j + 1);
-                iteration(ii, lb, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1 && bit(fetch, j + 2)); }, SaTrue{}, r0);
+                iteration(ii, lb, nx, [&] { issue_into(nx, ii + 2 * G + R, ii + 2 * G < i1 && bit(cfetch, j + 2)); }, SaTrue{}, r0, j);
                 if (r0) lb ^= 1;
-                iteration(ii + G, lb, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1 && bit(fetch, j + 3)); }, SaTrue{}, r1);
+                iteration(ii + G, lb, nxb, [&] { issue_into(nxb, ii + 3 * G + R, ii + 3 * G < i1 && bit(cfetch, j + 3)); }, SaTrue{}, r1, j + 1);
                 if (r1) lb ^= 1;
             }
         }
@@ -659,7 +706,7 @@ k_blur_fused(const float* __restrict__ in, float* __restrict__ out, float* __res
         for (int ii = i0; ii < i1; ii += G, ++j) {
             finish_rows();
             const bool run = !SPARSE || bit(need, j);
-            iteration(ii, buf, nx, [&] { if (ii + G < i1 && (!SPARSE || bit(fetch, j + 1))) issue_rows(ii + G + R); }, SaFalse{}, run);
+            iteration(ii, buf, nx, [&] { if (ii + G < i1 && (!SPARSE || bit(cfetch, j + 1))) issue_rows(ii + G + R); }, SaFalse{}, run, j);
             if (run) buf ^= (NBUF - 1);
         }
     }
