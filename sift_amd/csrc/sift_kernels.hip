@@ -2405,7 +2405,7 @@ static void blur_fused_t(hipStream_t st, const BlurArgs& a)
                              : ((a.w + 479) / 480) * 512 < ((a.w + 223) / 224) * 256;
     // Launches that compute only the needed parts decide per 8-row group of a tile, so narrow tiles skip
     // more: on the wide octaves, where an image has regions without contrast, they are the better choice
-    // (128 natural-like 1080p images, last image of octave 0: 1.35 ms against 1.95 with wide tiles, 2.2
+    // (128 natural-like 1080p images, last image of octave 0: 1.33 ms against 1.59 with wide tiles, 2.2
     // computed everywhere; white noise, nothing to skip: 2.5 against 2.45); the small octaves are needed
     // almost everywhere on every workload.  SIFT_AMD_SPARSE_WIDE=1/0 forces wide/narrow tiles for them.
     if (a.need_cells) {
